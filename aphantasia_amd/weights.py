@@ -1,0 +1,86 @@
+"""CLIP visual-tower weights: OpenAI checkpoint layout, loader and seeded synthetic init.
+
+The reference gets its weights from `clip.load(name)` (clip_fft.py:119), which
+downloads OpenAI's TorchScript archives.  There is no network on the build/bench
+machines, so benchmarks and parity tests use seeded synthetic weights with the
+same shapes and the same key layout ("Weights").
+"""
+import math
+
+import torch
+
+VIT_CONFIGS = {
+    'ViT-B/32': dict(input_resolution=224, patch_size=32, width=768, layers=12, heads=12, output_dim=512),
+    'ViT-B/16': dict(input_resolution=224, patch_size=16, width=768, layers=12, heads=12, output_dim=512),
+}
+
+
+def visual_config(name):
+    if name not in VIT_CONFIGS:
+        raise ValueError("only the ViT CLIP models are supported by the HIP path (%s); got %s"
+                         % (', '.join(VIT_CONFIGS), name))
+    return dict(VIT_CONFIGS[name])
+
+
+def synthetic_visual_weights(cfg, seed=1):
+    """Random weights following openai/CLIP's own constructor initialisation
+    (class/positional embeddings and proj ~ width**-0.5 * randn; conv/linear PyTorch
+    defaults; MHA in_proj xavier-uniform, zero biases).  fp32, OpenAI key layout
+    without the `visual.` prefix."""
+    g = torch.Generator().manual_seed(seed)
+    width, layers, p = cfg['width'], cfg['layers'], cfg['patch_size']
+    T = (cfg['input_resolution'] // p) ** 2 + 1
+    scale = width ** -0.5
+
+    def randn(*s):
+        return torch.randn(*s, generator=g)
+
+    def uniform(shape, bound):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * bound
+
+    w = {}
+    fan_in = 3 * p * p
+    w['conv1.weight'] = uniform((width, 3, p, p), 1.0 / math.sqrt(fan_in))
+    w['class_embedding'] = scale * randn(width)
+    w['positional_embedding'] = scale * randn(T, width)
+    w['ln_pre.weight'] = torch.ones(width)
+    w['ln_pre.bias'] = torch.zeros(width)
+    for i in range(layers):
+        pre = 'transformer.resblocks.%d.' % i
+        w[pre + 'attn.in_proj_weight'] = uniform((3 * width, width), math.sqrt(6.0 / (4 * width)))
+        w[pre + 'attn.in_proj_bias'] = torch.zeros(3 * width)
+        w[pre + 'attn.out_proj.weight'] = uniform((width, width), 1.0 / math.sqrt(width))
+        w[pre + 'attn.out_proj.bias'] = torch.zeros(width)
+        w[pre + 'ln_1.weight'] = torch.ones(width)
+        w[pre + 'ln_1.bias'] = torch.zeros(width)
+        w[pre + 'mlp.c_fc.weight'] = uniform((4 * width, width), 1.0 / math.sqrt(width))
+        w[pre + 'mlp.c_fc.bias'] = uniform((4 * width,), 1.0 / math.sqrt(width))
+        w[pre + 'mlp.c_proj.weight'] = uniform((width, 4 * width), 1.0 / math.sqrt(4 * width))
+        w[pre + 'mlp.c_proj.bias'] = uniform((width,), 1.0 / math.sqrt(4 * width))
+        w[pre + 'ln_2.weight'] = torch.ones(width)
+        w[pre + 'ln_2.bias'] = torch.zeros(width)
+    w['ln_post.weight'] = torch.ones(width)
+    w['ln_post.bias'] = torch.zeros(width)
+    w['proj'] = scale * randn(width, cfg['output_dim'])
+    return w
+
+
+def load_openai_checkpoint(path):
+    """Reads an OpenAI CLIP archive (`ViT-B-32.pt`, TorchScript) or a plain state-dict
+    file and returns (visual weights fp32 in the layout above, cfg, full state dict)."""
+    try:
+        sd = torch.jit.load(path, map_location='cpu').state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location='cpu')
+        if hasattr(sd, 'state_dict'):
+            sd = sd.state_dict()
+    if 'visual.proj' not in sd or 'visual.class_embedding' not in sd:
+        raise ValueError('%s is not a ViT CLIP checkpoint (no visual.proj)' % path)
+    vis = {k[len('visual.'):]: v.float() for k, v in sd.items() if k.startswith('visual.')}
+    width = vis['conv1.weight'].shape[0]
+    p = vis['conv1.weight'].shape[-1]
+    layers = len({k.split('.')[2] for k in vis if k.startswith('transformer.resblocks.')})
+    grid = round((vis['positional_embedding'].shape[0] - 1) ** 0.5)
+    cfg = dict(input_resolution=grid * p, patch_size=p, width=width, layers=layers,
+               heads=width // 64, output_dim=vis['proj'].shape[1])
+    return vis, cfg, sd

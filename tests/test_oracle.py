@@ -1,0 +1,143 @@
+"""CPU: the oracle restatement (oracle/) against (a) fixtures produced by the reference's
+own functions (tests/golden, made by oracle/make_goldens.py) and (b) the survey's KAT table."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_path as R
+from oracle import clip_vit_ref
+from aphantasia_amd.weights import synthetic_visual_weights, visual_config
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def test_kat_fft_params_and_rgb():
+    # SURVEY.md section 4 KAT rows 1-2 (values recorded from the reference itself)
+    seed_all(0)
+    p = R.fft_params_init([1, 3, 224, 224])
+    assert np.allclose(p[0, 0, 0, 0].numpy(), [-0.01125840, -0.01152360], atol=1e-8)
+    assert abs(p.sum().item() - (-2.690636396)) < 1e-4
+    scale = R.fft_scale(224, 224, 1.5)
+    img = R.synth_fft(p, scale, 224, 224, R.colcorr_t(1.8))
+    assert abs(img.mean().item() - 0.49129492) < 1e-6
+    assert abs(img.std().item() - 0.15267497) < 1e-6
+    assert np.allclose(img[0, :, 0, 0].numpy(), [0.49314794, 0.45017162, 0.58190310], atol=1e-6)
+    assert np.allclose(img[0, :, 100, 57].numpy(), [0.49892253, 0.43991053, 0.51003355], atol=1e-6)
+
+
+def test_kat_colcorr_and_scale():
+    cc = R.colcorr_t(1.8).numpy()
+    want = [[0.56282848, 0.58447582, 0.58447582], [0.35068548, 0, -0.35068548], [0.07793011, -0.19482526, 0.11689515]]
+    assert np.allclose(cc, want, atol=1e-7)
+    s = R.fft_scale(720, 1280, 1.5)
+    assert tuple(s.shape) == (720, 641)
+    assert abs(s.min().item() - 1614.5211) < 1e-2 and abs(s.max().item() - 5495360.66) < 1.0
+
+
+def test_kat_sim_func():
+    v1 = torch.sin(torch.arange(512.))[None]
+    v2 = torch.cos(torch.arange(1536.)).view(3, 512)
+    want = {None: 0.02639321, 'mix': -0.27291375, 'ang': 0.50846374, 'dot': 14.82776833}
+    for t, val in want.items():
+        assert abs(R.sim_func(v1, v2, t).item() - val) < 2e-5 * max(1, abs(val)), t
+    assert np.allclose(R.sim_func(v1, v2, 'spher').numpy(), [1.23344505, 1.36218655, 0.99605185], atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['synth_48x80.npz', 'synth_45x63.npz'])
+def test_synth_vs_reference_golden(golden, name):
+    g = golden(name)
+    h, w = int(g['h']), int(g['w'])
+    p = torch.from_numpy(g['params']).requires_grad_(True)
+    scale = R.fft_scale(h, w, float(g['decay']))
+    cc = R.colcorr_t(float(g['colors']))
+    raw = R.std_normalise(R.fft_image_raw(p, scale, h, w))
+    assert np.allclose(raw.detach().numpy(), g['raw'], atol=1e-6)
+    rgb = R.synth_fft(p, scale, h, w, cc, float(g['contrast']))
+    assert np.allclose(rgb.detach().numpy(), g['rgb'], atol=1e-6)
+    (rgb * torch.from_numpy(g['gw'])).sum().backward()
+    assert np.allclose(p.grad.numpy(), g['grad'], rtol=1e-5, atol=1e-5 * np.abs(g['grad']).max())
+
+
+@pytest.mark.parametrize('align', ['uniform', 'central', 'overscan', 'overmax'])
+def test_slice_vs_reference_golden(golden, align):
+    g = golden('slice_48x80.npz')
+    img = torch.from_numpy(g['img'])
+    seed_all(7)
+    table = R.draw_crop_table(6, 16, 48, 80, align, 0.4)
+    cuts = R.slice_imgs(img, table, 16, align)
+    assert np.array_equal(cuts.numpy(), g['cuts_' + align])
+
+
+def test_bicubic_matrix_matches_interpolate():
+    # the separable 4-tap restatement the HIP sampler implements == F.interpolate
+    x = torch.rand(1, 3, 301, 301, generator=torch.Generator().manual_seed(0))
+    for n in (225, 301):
+        ref = R.crop_resize(x, n, 0, 0, 224)
+        Wm = R.bicubic_matrix(n, 224)
+        got = torch.einsum('in,bcnm,jm->bcij', Wm, x[:, :, :n, :n], Wm)
+        assert (ref - got).abs().max().item() < 5e-6
+
+
+def test_sim_vs_reference_golden(golden):
+    g = golden('sim.npz')
+    v1 = torch.from_numpy(g['v1'])
+    for t in [None, 'mix', 'ang', 'dot']:
+        x = torch.from_numpy(g['v2']).requires_grad_(True)
+        val = R.sim_func(v1, x, t)
+        val.backward()
+        assert np.allclose(val.item(), g['val_%s' % t], rtol=1e-6)
+        assert np.allclose(x.grad.numpy(), g['grad_%s' % t], rtol=1e-5, atol=1e-7)
+
+
+def test_adam_explicit_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    for name, kw in [('adam_custom', dict(beta1=0.0)), ('adam', dict(beta1=0.9)),
+                     ('adamw', dict(beta1=0.9, weight_decay=0.01, decoupled=True)),
+                     ('adamw_custom', dict(beta1=0.0, weight_decay=0.01, decoupled=True, amsgrad=True))]:
+        p = torch.randn(1000, generator=g)
+        q = p.clone().requires_grad_(True)
+        opt = R.make_optimizer([q], name, 0.05)
+        m, v, vm = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(1, 5):
+            grad = torch.randn(1000, generator=g) * 10 ** float(torch.randn(1, generator=g))
+            q.grad = grad.clone()
+            opt.step()
+            R.adam_step(p, grad, m, v, vm, step, 0.05, **kw)
+            assert (p - q.detach()).abs().max().item() < 2e-6, name
+
+
+def test_run_vs_reference_golden(golden):
+    """oracle ReferenceRun == the reference's own functions, free-running 6 Adam steps."""
+    from oracle.make_goldens import TINY_VIT, tiny_weights
+    g = golden('run_40x56.npz')
+    w = tiny_weights(1)
+    run = R.ReferenceRun(int(g['h']), int(g['w']), lambda x: clip_vit_ref.encode_image(w, x, TINY_VIT),
+                         [(torch.from_numpy(g['target']), 1.0)], size=16, params=torch.from_numpy(g['params0']))
+    seed_all(123)
+    losses = []
+    for i in range(len(g['losses'])):
+        table = R.draw_crop_table(5, 16, run.h, run.w, 'uniform', 0.4)
+        losses.append(run.step(table))
+    assert np.allclose(losses, g['losses'], atol=1e-6)
+    assert np.allclose(run.params.detach().numpy(), g['params_final'], atol=1e-5)
+    with torch.no_grad():
+        assert np.allclose(run.image(1.1).numpy(), g['final'], atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['ViT-B/32', 'ViT-B/16'])
+def test_vit_restatement_vs_hf(name):
+    """openai/CLIP restatement == HF transformers CLIP vision tower (output and input-grad)."""
+    cfg = visual_config(name)
+    w = synthetic_visual_weights(cfg, 1)
+    hf = clip_vit_ref.hf_model(w, cfg)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(4)).requires_grad_(True)
+    a = clip_vit_ref.encode_image(w, x, cfg)
+    ga, = torch.autograd.grad(a.square().sum(), x)
+    x2 = x.detach().clone().requires_grad_(True)
+    b = hf(pixel_values=x2).image_embeds
+    gb, = torch.autograd.grad(b.square().sum(), x2)
+    assert (a - b).abs().max().item() < 2e-5 * b.abs().max().item() + 1e-5
+    assert (ga - gb).abs().max().item() < 1e-4 * gb.abs().max().item()
