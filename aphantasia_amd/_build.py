@@ -1,0 +1,51 @@
+"""Builds libaphantasia_hip.so (gfx950) in-tree with hipcc.  Called by __graft_entry__.build()."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, 'libaphantasia_hip.so')
+SOURCES = ['api.hip', 'synth.hip', 'sampler.hip', 'loss_adam.hip', 'vit.hip']
+
+
+def _stale():
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'aphantasia_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, 'build', src + '.o')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
+               '-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+        if verbose and out.strip():
+            print(out.decode(errors='replace'))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,105 @@
+// Device-side common definitions for the gfx950 kernels.
+// Product builds: hipcc --offload-arch=gfx950 (this header pulls in the HIP runtime).
+// The only other consumer is the test-only SIMT interpreter under tests/emu (APH_EMU),
+// which executes these same kernel sources on the build container's CPU for logic checks.
+#pragma once
+
+#ifdef APH_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define APH_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define APH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// kernels that ask for more than 64 KiB of dynamic LDS must opt in once
+#define APH_ALLOW_SMEM(kern, bytes) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#endif
+
+#include <stdint.h>
+
+namespace aph {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+// ---- wave / block reductions -------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    T o = __shfl_xor(v, m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64).  `red` = LDS scratch of >= 16 T.
+// Every thread gets the total.  Deterministic (fixed tree).
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();  // protect `red` reuse across consecutive calls
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  T t = 0;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---- matrix cores --------------------------------------------------------------
+// v_mfma_f32_16x16x32_f16:  D[16x16] += A[16x32] * B[32x16]
+//   A operand: lane l holds A[i = l & 15][k = (l >> 4) * 8 + j], j = 0..7
+//   B operand: lane l holds B[k = (l >> 4) * 8 + j][n = l & 15]
+//   C/D:       lane l, reg r holds D[i = (l >> 4) * 4 + r][n = l & 15]
+__device__ __forceinline__ f32x4 mfma_16x16x32_f16(half8 a, half8 b, f32x4 c) {
+#ifdef APH_EMU
+  struct Slot { half8 a, b; };
+  const int lane = emu::lane_id();
+  Slot s{a, b};
+  memcpy(emu::wave_slot(lane), &s, sizeof(s));
+  emu::wave_barrier();
+  const int n = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = (lane >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      Slot sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 16 * (k / 8)), sizeof(Slot));
+      memcpy(&sb, emu::wave_slot(n + 16 * (k / 8)), sizeof(Slot));
+      acc += (float)sa.a[k % 8] * (float)sb.b[k % 8];
+    }
+    c[r] = acc;
+  }
+  emu::wave_barrier();
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// v_dot2_f32_f16: c + a.x*b.x + a.y*b.y, fp32 accumulate
+__device__ __forceinline__ float dot2_f16(half2 a, half2 b, float c) {
+#ifdef APH_EMU
+  return c + (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1];
+#else
+  return __builtin_amdgcn_fdot2(a, b, c, false);
+#endif
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace aph

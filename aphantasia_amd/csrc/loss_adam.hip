@@ -1,0 +1,196 @@
+// Similarity loss (+ its gradient) and the fused Adam update.
+//
+// Replaces: aphantasia/utils.py:270-295 (sim_func / dot_compare) as assembled at clip_fft.py:257-267
+//           (loss = sum_t coef_t * sim_func(target_t, out_enc, type)), and torch.optim.Adam/AdamW as
+//           configured at clip_fft.py:108-115 (+ optimizer.step() at :295).
+#include "aph_device.h"
+#include "aph_host.h"
+
+namespace aph {
+
+enum { SIM_COS = 0, SIM_MIX = 1, SIM_ANG = 2, SIM_DOT = 3 };
+
+// One workgroup per sample: per-target value terms and d loss / d enc[s].
+//   enc [S,D] f32, tgt [T,D] f32, coef [T] f32 (sign*weight), denom = number of samples in the GLOBAL
+//   mean (S, or the all-rank total when samples are sharded across ranks).
+//   partial[s] = sum_t coef_t * (per-sample term) ; loss = sum_s partial[s] / denom   (not for SIM_DOT)
+__global__ void sim_loss_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, const float* __restrict__ coef,
+                                int T, int D, int type, float denom, float gscale, float* __restrict__ partial,
+                                float* __restrict__ genc) {
+  __shared__ float red[16];
+  const int s = blockIdx.x;
+  const float* e = enc + (size_t)s * D;
+  float ee = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) ee += e[d] * e[d];
+  ee = block_sum(ee, red);
+  const float ne = sqrtf(ee);
+  float total = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) genc[(size_t)s * D + d] = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float* v = tgt + (size_t)t * D;
+    float dot = 0.f, vv = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) { dot += v[d] * e[d]; vv += v[d] * v[d]; }
+    dot = block_sum(dot, red);
+    vv = block_sum(vv, red);
+    const float nv = sqrtf(vv);
+    // torch.cosine_similarity: x.y / max(|x| |y|, eps), eps = 1e-8
+    const float den = fmaxf(ne * nv, 1e-8f);
+    const float c = dot / den;
+    float val, dval_dc;
+    if (type == SIM_MIX) {
+      // spher = 2 asin(|v^ - e^| / 2)^2 with |v^ - e^|^2 = 2 - 2c  (utils.py:279-282)
+      float dd = fmaxf(2.f - 2.f * c, 0.f);
+      const float dist = sqrtf(dd);
+      const float h = fminf(dist * 0.5f, 1.0f);
+      const float a = asinf(h);
+      val = c - 0.25f * (2.f * a * a);
+      // d(0.5 a^2)/dc = a * da/dc,  da/dc = -1 / (2 dist sqrt(1 - dist^2/4))
+      const float sq = sqrtf(fmaxf(1.f - h * h, 1e-12f));
+      const float dadc = dist > 1e-6f ? -1.f / (2.f * dist * sq) : -0.5f;   // limit as dist -> 0: a ~ dist/2
+      dval_dc = 1.f - a * dadc * 1.0f;
+      dval_dc = 1.f - (a * dadc);   // val = c - 0.5 a^2
+    } else if (type == SIM_ANG) {
+      const float cc = fminf(fmaxf(c, -1.f), 1.f);
+      val = -acosf(cc) * 0.31830988618379067f;          // the constant 1 is added on the host side
+      dval_dc = 0.31830988618379067f / sqrtf(fmaxf(1.f - cc * cc, 1e-12f));
+    } else {
+      val = c;
+      dval_dc = 1.f;
+    }
+    total += coef[t] * val;
+    // dc/de = v / den - c * e / |e|^2
+    const float k = coef[t] * dval_dc * gscale / denom;
+    const float inv_ee = ee > 0.f ? 1.f / ee : 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) genc[(size_t)s * D + d] += k * (v[d] / den - c * e[d] * inv_ee);
+  }
+  if (threadIdx.x == 0) partial[s] = total;
+}
+
+// 'dot' similarity (dot_compare, utils.py:270-274): global over all samples:
+//   dot = sum_{s,d} v[d] e[s,d]; mag = sqrt(sum e^2); loss_t = dot * dot / (1e-6 + mag)
+// Pass 1: per-sample partial sums (dotsum per target, sumsq);  pass 2: gradient.
+__global__ void sim_dot_partial_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, int T, int D,
+                                       float* __restrict__ part /*[S, T+1]*/) {
+  __shared__ float red[16];
+  const int s = blockIdx.x;
+  const float* e = enc + (size_t)s * D;
+  float ee = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) ee += e[d] * e[d];
+  ee = block_sum(ee, red);
+  if (threadIdx.x == 0) part[(size_t)s * (T + 1) + T] = ee;
+  for (int t = 0; t < T; ++t) {
+    float dot = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dot += tgt[(size_t)t * D + d] * e[d];
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) part[(size_t)s * (T + 1) + t] = dot;
+  }
+}
+__global__ void sim_dot_grad_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, const float* __restrict__ coef,
+                                    const float* __restrict__ part, int S, int T, int D, float gscale,
+                                    float* __restrict__ loss_out, float* __restrict__ genc) {
+  __shared__ float sums[64];
+  // every block recomputes the global sums deterministically (S, T are small)
+  if ((int)threadIdx.x <= T && threadIdx.x < 64) {
+    double a = 0.0;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * (T + 1) + threadIdx.x];
+    sums[threadIdx.x] = (float)a;
+  }
+  __syncthreads();
+  const float mag = sqrtf(sums[T]);
+  const int s = blockIdx.x;
+  float loss = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float g = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float dot = sums[t];
+      // f = dot^2 / (1e-6 + mag): df/de = 2 dot v / (eps+mag) - dot^2 / (eps+mag)^2 * e / mag
+      const float q = 1e-6f + mag;
+      g += coef[t] * (2.f * dot * tgt[(size_t)t * D + d] / q - dot * dot / (q * q) * (mag > 0.f ? enc[(size_t)s * D + d] / mag : 0.f));
+    }
+    genc[(size_t)s * D + d] = g * gscale;
+  }
+  if (s == 0 && threadIdx.x == 0) {
+    for (int t = 0; t < T; ++t) loss += coef[t] * sums[t] * sums[t] / (1e-6f + mag);
+    loss_out[0] = loss;
+  }
+}
+
+// loss = base + sum_s partial[s] / denom  (single block)
+__global__ void loss_reduce_kernel(const float* __restrict__ partial, int S, float denom, float base, float* __restrict__ loss_out) {
+  __shared__ double red[16];
+  double a = 0.0;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) a += partial[s];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) loss_out[0] = base + (float)(a / denom);
+}
+
+// ---------------------------------------------------------------------------------
+// Adam / AdamW (torch.optim semantics, single tensor).  hyper = device floats so a captured graph
+// can be replayed with new step / lr:  {lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt(bias_corr2), gradscale}
+// ---------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vmax, const float* __restrict__ hyper, int decoupled, size_t n) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], sbc2 = hyper[6],
+              gs = hyper[7];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float pi = p[i], gi = g[i] * gs;
+    if (wd != 0.f) {
+      if (decoupled) pi *= (1.f - lr * wd);
+      else gi += wd * pi;
+    }
+    float mi = gi;
+    if (m) { mi = b1 * m[i] + (1.f - b1) * gi; m[i] = mi; }
+    else mi = (1.f - b1) * gi;   // beta1 == 0 path keeps no first-moment buffer
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    v[i] = vi;
+    if (vmax) { const float mx = fmaxf(vmax[i], vi); vmax[i] = mx; vi = mx; }
+    const float denom = sqrtf(vi) / sbc2 + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace aph
+
+using namespace aph;
+
+extern "C" {
+
+// sim_func(target_t, enc, type) summed over targets with coefficients, value and gradient in one pass.
+// type: 0 cossim (None), 1 mix, 2 ang, 3 dot.  d_ws: f32 scratch of S*(T+2) elements.
+// loss (device scalar) = sum_t coef_t * sim_t ;  d_genc = gscale * d loss / d enc.
+// denom: sample count of the global mean (== S unless samples are sharded over ranks).
+int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const float* d_coef, const float* h_coef, int T,
+                 int type, float denom, float gscale, float* d_ws, float* d_loss, float* d_genc, void* stream_) {
+  APH_TRY
+  if (!d_enc || !d_targets || !d_coef || !d_ws || !d_loss || !d_genc || S < 1 || D < 1 || T < 1 || T > 62)
+    return aph_fail(APH_ERR_ARG, "aph_sim_loss: bad argument (S=%d D=%d T=%d)", S, D, T);
+  if (type < 0 || type > 3) return aph_fail(APH_ERR_ARG, "aph_sim_loss: unknown similarity type %d", type);
+  hipStream_t st = (hipStream_t)stream_;
+  if (type == SIM_DOT) {
+    APH_LAUNCH(sim_dot_partial_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, T, D, d_ws);
+    APH_LAUNCH(sim_dot_grad_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, (const float*)d_ws, S, T, D, gscale, d_loss, d_genc);
+    return aph_check_launch("aph_sim_loss");
+  }
+  float base = 0.f;
+  if (type == SIM_ANG) {   // 1 - acos(.)mean/pi : the constant part
+    if (!h_coef) return aph_fail(APH_ERR_ARG, "aph_sim_loss: 'ang' needs host coefficients");
+    for (int t = 0; t < T; ++t) base += h_coef[t];
+  }
+  APH_LAUNCH(sim_loss_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, T, D, type, denom, gscale, d_ws, d_genc);
+  APH_LAUNCH(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)d_ws, S, denom, base, d_loss);
+  return aph_check_launch("aph_sim_loss");
+  APH_CATCH
+}
+
+// One optimizer.step() on a flat f32 tensor.  d_m may be NULL when beta1 == 0; d_vmax NULL unless amsgrad.
+// d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale}.
+int aph_adam_step(float* d_p, const float* d_g, float* d_m, float* d_v, float* d_vmax, const float* d_hyper, int decoupled_wd,
+                  size_t n, void* stream_) {
+  APH_TRY
+  if (!d_p || !d_g || !d_v || !d_hyper) return aph_fail(APH_ERR_ARG, "aph_adam_step: null argument");
+  APH_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, d_p, d_g, d_m, d_v, d_vmax, d_hyper, decoupled_wd, n);
+  return aph_check_launch("aph_adam_step");
+  APH_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// CLIP ViT visual tower: `model.encode_image(x)` forward and its INPUT-gradient backward
+// (clip_fft.py:254 and the autograd pass of clip_fft.py:294 through it).  Weight gradients are
+// never formed -- the optimisation only updates the image parameters.
+//
+// fp16 operands / fp32 accumulation on the matrix cores, fp32 residual stream, fp32 LayerNorm and
+// softmax statistics; the backward chain carries a static loss scale (applied by the caller to
+// d_enc, removed by `out_scale`) so fp16 gradient activations do not underflow.
+#include <cstring>
+#include <string>
+
+#include "aph_device.h"
+#include "aph_host.h"
+#include "vit_gemm.h"
+#include "vit_ops.h"
+
+using namespace aph;
+
+namespace {
+
+struct Layer {
+  half_t *w_qkv = nullptr, *w_qkvT = nullptr, *w_o = nullptr, *w_oT = nullptr;
+  half_t *w_fc1 = nullptr, *w_fc1T = nullptr, *w_fc2 = nullptr, *w_fc2T = nullptr;
+  float *b_qkv = nullptr, *b_o = nullptr, *b_fc1 = nullptr, *b_fc2 = nullptr;
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  // per-layer activations kept for the backward
+  float *x_in = nullptr, *x_mid = nullptr, *lse = nullptr;
+  half_t *qkv = nullptr, *att = nullptr, *u = nullptr;
+};
+
+}  // namespace
+
+struct aph_vit {
+  int res, patch, D, L, heads, E, T, P, Kp, max_batch;
+  half_t *w_patch = nullptr, *w_patchT = nullptr;
+  float *cls = nullptr, *pos = nullptr, *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
+  float *proj = nullptr, *projT = nullptr;
+  std::vector<Layer> layers;
+  float *x0 = nullptr, *x_last = nullptr;
+  half_t *h = nullptr, *gact = nullptr;
+  float* dx = nullptr;
+  half_t *dx16 = nullptr, *du = nullptr, *dh = nullptr, *datt = nullptr, *dqkv = nullptr, *dx0_16 = nullptr;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int n_set = 0;
+};
+
+namespace {
+
+struct Carver {
+  char* base; size_t off = 0;
+  template <typename T> T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (n * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+
+void carve(aph_vit* v, char* base, size_t* total) {
+  Carver c{base};
+  const size_t D = v->D, Mx = (size_t)v->max_batch * v->T, E = v->E, Kp = v->Kp, T = v->T;
+  v->w_patch = c.take<half_t>(D * Kp); v->w_patchT = c.take<half_t>(D * Kp);
+  v->cls = c.take<float>(D); v->pos = c.take<float>(T * D);
+  v->ln_pre_g = c.take<float>(D); v->ln_pre_b = c.take<float>(D);
+  v->ln_post_g = c.take<float>(D); v->ln_post_b = c.take<float>(D);
+  v->proj = c.take<float>(D * E); v->projT = c.take<float>(D * E);
+  for (auto& l : v->layers) {
+    l.w_qkv = c.take<half_t>(3 * D * D); l.w_qkvT = c.take<half_t>(3 * D * D);
+    l.w_o = c.take<half_t>(D * D); l.w_oT = c.take<half_t>(D * D);
+    l.w_fc1 = c.take<half_t>(4 * D * D); l.w_fc1T = c.take<half_t>(4 * D * D);
+    l.w_fc2 = c.take<half_t>(4 * D * D); l.w_fc2T = c.take<half_t>(4 * D * D);
+    l.b_qkv = c.take<float>(3 * D); l.b_o = c.take<float>(D); l.b_fc1 = c.take<float>(4 * D); l.b_fc2 = c.take<float>(D);
+    l.ln1_g = c.take<float>(D); l.ln1_b = c.take<float>(D); l.ln2_g = c.take<float>(D); l.ln2_b = c.take<float>(D);
+    l.x_in = c.take<float>(Mx * D); l.x_mid = c.take<float>(Mx * D); l.lse = c.take<float>((size_t)v->max_batch * v->heads * T);
+    l.qkv = c.take<half_t>(Mx * 3 * D); l.att = c.take<half_t>(Mx * D); l.u = c.take<half_t>(Mx * 4 * D);
+  }
+  v->x0 = c.take<float>(Mx * D); v->x_last = c.take<float>(Mx * D);
+  v->h = c.take<half_t>(Mx * D); v->gact = c.take<half_t>(Mx * 4 * D);
+  v->dx = c.take<float>(Mx * D);
+  v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
+  v->datt = c.take<half_t>(Mx * D); v->dqkv = c.take<half_t>(Mx * 3 * D); v->dx0_16 = c.take<half_t>(Mx * D);
+  *total = c.off;
+}
+
+// host fp32 [rows, cols] -> device fp16, optionally transposed
+int upload_f16(half_t* dst, const float* src, size_t rows, size_t cols, bool transpose) {
+  std::vector<half_t> tmp(rows * cols);
+  if (!transpose) {
+    for (size_t i = 0; i < rows * cols; ++i) tmp[i] = (half_t)src[i];
+  } else {
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < cols; ++c) tmp[c * rows + r] = (half_t)src[r * cols + c];
+  }
+  return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+int upload_f32(float* dst, const float* src, size_t rows, size_t cols, bool transpose) {
+  if (!transpose) return hipMemcpy(dst, src, rows * cols * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+  std::vector<float> tmp(rows * cols);
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < cols; ++c) tmp[c * rows + r] = src[r * cols + c];
+  return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
+template <bool OUT_F16, bool CLS>
+void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void* out, int M, int T, const float* cls,
+                   const float* pos, float* x_fill, hipStream_t st) {
+  const dim3 grid((M + 3) / 4), block(256);
+  switch (nv) {
+    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
+    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
+    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
+    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
+  }
+}
+template <bool DY_F16, bool PATCH>
+void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const float* res, float* out32, half_t* out16, int M,
+                   int T, hipStream_t st) {
+  const dim3 grid((M + 3) / 4), block(256);
+  switch (nv) {
+    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
+    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
+    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
+    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// cfg mirrors clip.model.VisionTransformer(input_resolution, patch_size, width, layers, heads, output_dim)
+int aph_vit_create(int input_resolution, int patch_size, int width, int layers, int heads, int output_dim, int max_batch,
+                   aph_vit** out) {
+  APH_TRY
+  if (!out) return aph_fail(APH_ERR_ARG, "aph_vit_create: null out");
+  if (width % 256 || width > 1024 || heads * kHeadDim != width)
+    return aph_fail(APH_ERR_UNSUPPORTED, "aph_vit_create: width %d / heads %d unsupported (need head dim 64, width in {256,512,768,1024})", width, heads);
+  if (input_resolution % patch_size || (3 * patch_size * patch_size) % 128 || output_dim < 1 || layers < 1 || max_batch < 1)
+    return aph_fail(APH_ERR_UNSUPPORTED, "aph_vit_create: resolution %d / patch %d unsupported", input_resolution, patch_size);
+  auto* v = new aph_vit();
+  v->res = input_resolution; v->patch = patch_size; v->D = width; v->L = layers; v->heads = heads; v->E = output_dim;
+  const int g = input_resolution / patch_size;
+  v->P = g * g; v->T = v->P + 1; v->Kp = 3 * patch_size * patch_size; v->max_batch = max_batch;
+  if (v->T > 256) { delete v; return aph_fail(APH_ERR_UNSUPPORTED, "aph_vit_create: %d tokens per image not supported", v->T); }
+  v->layers.resize(layers);
+  size_t total = 0;
+  carve(v, nullptr, &total);
+  if (hipMalloc((void**)&v->arena, total) != hipSuccess) { delete v; return aph_fail(APH_ERR_HIP, "aph_vit_create: cannot allocate %zu bytes", total); }
+  v->arena_bytes = total;
+  carve(v, v->arena, &total);
+  const size_t bwd_smem = (size_t)4 * v->T * 128 + 8 * v->T;
+  APH_ALLOW_SMEM(attn_bwd_kernel, bwd_smem);
+  APH_ALLOW_SMEM(attn_fwd_kernel, (size_t)2 * v->T * 128);
+  *out = v;
+  return APH_OK;
+  APH_CATCH
+}
+
+int aph_vit_destroy(aph_vit* v) {
+  if (!v) return APH_OK;
+  (void)hipFree(v->arena);
+  delete v;
+  return APH_OK;
+}
+
+size_t aph_vit_workspace_bytes(const aph_vit* v) { return v ? v->arena_bytes : 0; }
+
+// Upload one tensor by its OpenAI checkpoint key (without the `visual.` prefix), fp32 host data.
+// e.g. "conv1.weight", "transformer.resblocks.3.attn.in_proj_weight", "proj".
+int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t count) {
+  APH_TRY
+  if (!v || !name || !data) return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: null argument");
+  const size_t D = v->D, E = v->E, Kp = v->Kp, T = v->T;
+  const std::string n(name);
+  auto need = [&](size_t want) { return count == want ? 0 : aph_fail(APH_ERR_ARG, "aph_vit_set_weight(%s): %zu elements, expected %zu", name, count, want); };
+  int rc = 0;
+  if (n == "conv1.weight") { if ((rc = need(D * Kp))) return rc; rc = upload_f16(v->w_patch, data, D, Kp, false) | upload_f16(v->w_patchT, data, D, Kp, true); }
+  else if (n == "class_embedding") { if ((rc = need(D))) return rc; rc = upload_f32(v->cls, data, 1, D, false); }
+  else if (n == "positional_embedding") { if ((rc = need(T * D))) return rc; rc = upload_f32(v->pos, data, T, D, false); }
+  else if (n == "ln_pre.weight") { if ((rc = need(D))) return rc; rc = upload_f32(v->ln_pre_g, data, 1, D, false); }
+  else if (n == "ln_pre.bias") { if ((rc = need(D))) return rc; rc = upload_f32(v->ln_pre_b, data, 1, D, false); }
+  else if (n == "ln_post.weight") { if ((rc = need(D))) return rc; rc = upload_f32(v->ln_post_g, data, 1, D, false); }
+  else if (n == "ln_post.bias") { if ((rc = need(D))) return rc; rc = upload_f32(v->ln_post_b, data, 1, D, false); }
+  else if (n == "proj") { if ((rc = need(D * E))) return rc; rc = upload_f32(v->proj, data, D, E, false) | upload_f32(v->projT, data, D, E, true); }
+  else if (n.rfind("transformer.resblocks.", 0) == 0) {
+    const size_t p0 = strlen("transformer.resblocks.");
+    const size_t dot = n.find('.', p0);
+    if (dot == std::string::npos) return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: bad key %s", name);
+    const int li = atoi(n.substr(p0, dot - p0).c_str());
+    if (li < 0 || li >= v->L) return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: layer %d out of range", li);
+    Layer& l = v->layers[li];
+    const std::string k = n.substr(dot + 1);
+    if (k == "attn.in_proj_weight") { if ((rc = need(3 * D * D))) return rc; rc = upload_f16(l.w_qkv, data, 3 * D, D, false) | upload_f16(l.w_qkvT, data, 3 * D, D, true); }
+    else if (k == "attn.in_proj_bias") { if ((rc = need(3 * D))) return rc; rc = upload_f32(l.b_qkv, data, 1, 3 * D, false); }
+    else if (k == "attn.out_proj.weight") { if ((rc = need(D * D))) return rc; rc = upload_f16(l.w_o, data, D, D, false) | upload_f16(l.w_oT, data, D, D, true); }
+    else if (k == "attn.out_proj.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.b_o, data, 1, D, false); }
+    else if (k == "ln_1.weight") { if ((rc = need(D))) return rc; rc = upload_f32(l.ln1_g, data, 1, D, false); }
+    else if (k == "ln_1.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.ln1_b, data, 1, D, false); }
+    else if (k == "ln_2.weight") { if ((rc = need(D))) return rc; rc = upload_f32(l.ln2_g, data, 1, D, false); }
+    else if (k == "ln_2.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.ln2_b, data, 1, D, false); }
+    else if (k == "mlp.c_fc.weight") { if ((rc = need(4 * D * D))) return rc; rc = upload_f16(l.w_fc1, data, 4 * D, D, false) | upload_f16(l.w_fc1T, data, 4 * D, D, true); }
+    else if (k == "mlp.c_fc.bias") { if ((rc = need(4 * D))) return rc; rc = upload_f32(l.b_fc1, data, 1, 4 * D, false); }
+    else if (k == "mlp.c_proj.weight") { if ((rc = need(4 * D * D))) return rc; rc = upload_f16(l.w_fc2, data, D, 4 * D, false) | upload_f16(l.w_fc2T, data, D, 4 * D, true); }
+    else if (k == "mlp.c_proj.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.b_fc2, data, 1, D, false); }
+    else return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: unknown key %s", name);
+  } else return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: unknown key %s", name);
+  if (rc) return aph_fail(APH_ERR_HIP, "aph_vit_set_weight(%s): upload failed", name);
+  v->n_set++;
+  return APH_OK;
+  APH_CATCH
+}
+
+// encode_image: d_patches f16 [S*P, 3*patch*patch] (patch-major, CLIP-normalised) -> d_enc f32 [S, output_dim]
+int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void* stream_) {
+  APH_TRY
+  if (!v || !d_patches || !d_enc) return aph_fail(APH_ERR_ARG, "aph_vit_forward: null argument");
+  if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_forward: batch %d outside 1..%d", S, v->max_batch);
+  if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_forward: weights not fully loaded (%d tensors)", v->n_set);
+  hipStream_t st = (hipStream_t)stream_;
+  const int D = v->D, T = v->T, M = S * T, nv = D / 256;
+  launch_gemm((const half_t*)d_patches, v->Kp, v->w_patch, v->Kp, S * v->P, D, v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
+  launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st);
+  for (int li = 0; li < v->L; ++li) {
+    Layer& l = v->layers[li];
+    float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
+    launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
+    launch_gemm(v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+    APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
+    launch_gemm(l.att, D, l.w_o, D, M, D, D, EpiResidual{l.x_mid, l.x_in, D, l.b_o}, st);
+    launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, M, T, nullptr, nullptr, nullptr, st);
+    launch_gemm(v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
+    launch_gemm(v->gact, 4 * D, l.w_fc2, 4 * D, M, D, 4 * D, EpiResidual{x_next, l.x_mid, D, l.b_fc2}, st);
+  }
+  APH_LAUNCH(head_fwd_kernel, dim3(S), dim3(256), sizeof(float) * D, st, (const float*)v->x_last, (const float*)v->ln_post_g,
+             (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
+  return aph_check_launch("aph_vit_forward");
+  APH_CATCH
+}
+
+// input-gradient of the last aph_vit_forward: d_genc f32 [S, output_dim] (already multiplied by the caller's
+// loss scale) -> d_patch_grad f32 [S*P, 3*patch*patch] multiplied by out_scale (pass 1/loss_scale).
+int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream_) {
+  APH_TRY
+  if (!v || !d_genc || !d_patch_grad) return aph_fail(APH_ERR_ARG, "aph_vit_backward: null argument");
+  if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
+  hipStream_t st = (hipStream_t)stream_;
+  const int D = v->D, T = v->T, M = S * T, nv = D / 256;
+  APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(256), sizeof(float) * (v->E + 2 * D), st, d_genc, (const float*)v->x_last,
+             (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
+  for (int li = v->L - 1; li >= 0; --li) {
+    Layer& l = v->layers[li];
+    launch_gemm(v->dx16, D, l.w_fc2T, D, M, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+    launch_gemm(v->du, 4 * D, l.w_fc1T, 4 * D, M, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
+    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, M, T, st);
+    launch_gemm(v->dx16, D, l.w_oT, D, M, D, D, EpiF16{v->datt, D, nullptr}, st);
+    APH_LAUNCH(attn_bwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)4 * T * 128 + 8 * T, st, (const half_t*)l.qkv,
+               (const half_t*)l.att, (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+    launch_gemm(v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
+    launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
+  }
+  launch_ln_bwd<false, true>(nv, v->dx, v->x0, v->ln_pre_g, nullptr, nullptr, v->dx0_16, M, T, st);
+  launch_gemm(v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{d_patch_grad, v->Kp, out_scale}, st);
+  return aph_check_launch("aph_vit_backward");
+  APH_CATCH
+}
+
+// plain C = A * Bt^T (f16 in, f32 out) -- exported for the GEMM unit tests and micro-benchmarks
+int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream_) {
+  APH_TRY
+  if (!d_A || !d_Bt || !d_C || M < 1 || N % GEMM_BN || K % GEMM_BK || N < 1 || K < 1)
+    return aph_fail(APH_ERR_ARG, "aph_gemm_f16: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+  launch_gemm((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
+  return aph_check_launch("aph_gemm_f16");
+  APH_CATCH
+}
+
+}  // extern "C"

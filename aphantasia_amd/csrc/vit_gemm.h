@@ -1,0 +1,186 @@
+// fp16-in / fp32-accumulate MFMA GEMM for the CLIP ViT linears, gfx950.
+//
+//   C[m][n] = sum_k A[m][k] * Bt[n][k]        A: [M,K] f16 row-major, Bt: [N,K] f16 row-major
+//
+// Both operands are K-contiguous, so the forward (activations x weight^T) and the dgrad
+// (d_out x weight, using a pre-transposed weight copy) run through the same kernel.
+// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_f16 tiles.
+// Global -> registers -> LDS staging with the next tile's loads in flight during the MFMAs
+// (T14 split), 16-byte XOR-swizzled LDS chunks so every ds_read_b128 fragment fetch is
+// conflict-free (cdna_hip_programming.md section 5 / Guideline 4).
+// Operands are swapped at the MFMA (weights as the A fragment) so each lane ends up holding
+// 4 CONSECUTIVE output columns of one output row -> 16-byte epilogue accesses.
+//
+// Constraints: N % 128 == 0, K % 64 == 0 (true for every ViT-B linear); M is arbitrary
+// (loads clamp the row, stores are predicated).
+#pragma once
+#include "aph_device.h"
+
+namespace aph {
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
+
+// LDS tile: [128 rows][8 chunks of 8 halfs]; chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7)
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <class Epi>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
+                                                       int ldb, int M, int N, int K, Epi epi) {
+  __shared__ __attribute__((aligned(16))) half_t lds[2 * GEMM_BM * GEMM_BK];
+  half_t* As = lds;
+  half_t* Bs = lds + GEMM_BM * GEMM_BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM;
+
+  // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
+  const half_t* ga[4];
+  const half_t* gb[4];
+  int so[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = tid + 256 * r, row = q >> 3, c = q & 7;
+    int am = m0 + row; am = am < M ? am : M - 1;
+    ga[r] = A + (size_t)am * lda + c * 8;
+    gb[r] = Bt + (size_t)(n0 + row) * ldb + c * 8;
+    so[r] = lds_off(row, c);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  half8 ra[4], rb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ra[r] = *reinterpret_cast<const half8*>(ga[r]);
+    rb[r] = *reinterpret_cast<const half8*>(gb[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    *reinterpret_cast<half8*>(As + so[r]) = ra[r];
+    *reinterpret_cast<half8*>(Bs + so[r]) = rb[r];
+  }
+  __syncthreads();
+
+  const int nk = K / GEMM_BK;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      const int ko = (kt + 1) * GEMM_BK;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ra[r] = *reinterpret_cast<const half8*>(ga[r] + ko);
+        rb[r] = *reinterpret_cast<const half8*>(gb[r] + ko);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = *reinterpret_cast<const half8*>(As + lds_off(wm * 64 + t * 16 + frow, kk * 4 + fchunk));
+        fb[t] = *reinterpret_cast<const half8*>(Bs + lds_off(wn * 64 + t * 16 + frow, kk * 4 + fchunk));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_16x16x32_f16(fb[nt], fa[mt], acc[mt][nt]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<half8*>(As + so[r]) = ra[r];
+        *reinterpret_cast<half8*>(Bs + so[r]) = rb[r];
+      }
+      __syncthreads();
+    }
+  }
+
+  // lane (l) reg r of tile (mt, nt):  row m = .. + (l & 15), cols n = .. + (l >> 4) * 4 + r
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
+    if (m < M) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) epi(m, n0 + wn * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
+    }
+  }
+}
+
+// ---- epilogues (called with 4 consecutive columns n..n+3 of row m) ---------------------------
+__device__ __forceinline__ void store_h4(half_t* p, float a, float b, float c, float d) {
+  half4 h = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
+  *reinterpret_cast<half4*>(p) = h;
+}
+
+struct EpiF16 {          // out = acc (+ bias)
+  half_t* out; int ldo; const float* bias;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n); v += b; }
+    store_h4(out + (size_t)m * ldo + n, v[0], v[1], v[2], v[3]);
+  }
+};
+
+struct EpiF32 {          // out = acc * scale  (fp32)
+  float* out; int ldo; float scale;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + n) = v * scale;
+  }
+};
+
+struct EpiResidual {     // out = res + acc + bias   (fp32 residual stream)
+  float* out; const float* res; int ldo; const float* bias;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(res + (size_t)m * ldo + n);
+    *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + n) = r + v + b;
+  }
+};
+
+struct EpiGelu {         // u = acc + bias (kept for the backward), g = u * sigmoid(1.702 u)   [QuickGELU]
+  half_t* u; half_t* g; int ldo; const float* bias;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    v += *reinterpret_cast<const f32x4*>(bias + n);
+    store_h4(u + (size_t)m * ldo + n, v[0], v[1], v[2], v[3]);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+    store_h4(g + (size_t)m * ldo + n, o[0], o[1], o[2], o[3]);
+  }
+};
+
+struct EpiGeluBwd {      // du = acc * d/du [u sigmoid(1.702 u)]
+  half_t* out; const half_t* u; int ldo;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    const half4 uh = *reinterpret_cast<const half4*>(u + (size_t)m * ldo + n);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x = (float)uh[i];
+      const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      o[i] = v[i] * (s * (1.0f + 1.702f * x * (1.0f - s)));
+    }
+    store_h4(out + (size_t)m * ldo + n, o[0], o[1], o[2], o[3]);
+  }
+};
+
+struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + positional embedding
+  float* x0; const float* pos; int D, P, T;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    const int s = m / P, p = m - s * P;
+    const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (size_t)(1 + p) * D + n);
+    *reinterpret_cast<f32x4*>(x0 + ((size_t)s * T + 1 + p) * D + n) = v + pe;
+  }
+};
+
+template <class Epi>
+inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+  APH_LAUNCH(gemm_f16_kernel<Epi>, dim3(N / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, epi);
+}
+
+}  // namespace aph

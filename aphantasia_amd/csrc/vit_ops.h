@@ -1,0 +1,351 @@
+// Non-GEMM kernels of the CLIP ViT forward / input-gradient backward:
+// LayerNorm (fp32 statistics), small-sequence multi-head attention (T = 50 / 197, head dim 64),
+// class-token / positional embedding, ln_post + projection head.
+// Follows openai/CLIP clip/model.py VisionTransformer / ResidualAttentionBlock (see
+// oracle/clip_vit_ref.py for the restatement these kernels are tested against).
+#pragma once
+#include "aph_device.h"
+
+namespace aph {
+
+constexpr float kLnEps = 1e-5f;
+constexpr int kHeadDim = 64;
+
+// ---------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, row held in registers (D = 256 * NV).
+// OUT_F16: h = LN(x) as f16 (GEMM operand);  else fp32 (ln_pre, feeding the residual stream).
+// CLS_FILL: row t == 0 of every image is read as class_embedding + pos[0] (the patch-embed GEMM
+//           only writes token rows 1..T-1) -- used by ln_pre.
+// ---------------------------------------------------------------------------------
+template <int NV, bool OUT_F16, bool CLS_FILL>
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              void* __restrict__ out, int M, int T, const float* __restrict__ cls, const float* __restrict__ pos,
+                              float* __restrict__ x_fill) {
+  constexpr int D = 256 * NV;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v[NV];
+  const bool fill = CLS_FILL && (row % T == 0);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = i * 256 + lane * 4;
+    if (fill) {
+      v[i] = *reinterpret_cast<const f32x4*>(cls + d) + *reinterpret_cast<const f32x4*>(pos + d);
+      *reinterpret_cast<f32x4*>(x_fill + (size_t)row * D + d) = v[i];
+    } else {
+      v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + d);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float c = v[i][j] - mean; q += c * c; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + kLnEps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = i * 256 + lane * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + d), b = *reinterpret_cast<const f32x4*>(beta + d);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+    if (OUT_F16) {
+      half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+      *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(out) + (size_t)row * D + d) = h;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)row * D + d) = o;
+    }
+  }
+}
+
+// LayerNorm input-gradient:  dx = [res +] rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+// x = the LN input (statistics are recomputed from it), dy f16 or f32, res = incoming residual-stream
+// gradient (fp32) or NULL.  Writes fp32 (out32, optional) and/or f16 (out16, optional).
+// PATCH_ROWS: out16 row index is compacted s*T + t -> s*(T-1) + t-1 and class rows are dropped
+// (feeds the patch-embedding dgrad GEMM).
+template <int NV, bool DY_F16, bool PATCH_ROWS>
+__global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ res, float* __restrict__ out32, half_t* __restrict__ out16, int M, int T) {
+  constexpr int D = 256 * NV;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v[NV], g[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = i * 256 + lane * 4;
+    v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + d);
+    f32x4 dyv;
+    if (DY_F16) {
+      const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(dy) + (size_t)row * D + d);
+      dyv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+      dyv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + (size_t)row * D + d);
+    }
+    g[i] = dyv * *reinterpret_cast<const f32x4*>(gamma + d);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + kLnEps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[i][j] *= rstd; sg += g[i][j]; sgx += g[i][j] * v[i][j]; }
+  sg = wave_sum(sg) * (1.0f / D);
+  sgx = wave_sum(sgx) * (1.0f / D);
+  int orow = row;
+  if (PATCH_ROWS) {
+    const int s_ = row / T, t_ = row - s_ * T;
+    if (t_ == 0) return;
+    orow = s_ * (T - 1) + t_ - 1;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = i * 256 + lane * 4;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - sg - v[i][j] * sgx);
+    if (res) o += *reinterpret_cast<const f32x4*>(res + (size_t)row * D + d);
+    if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)row * D + d) = o;
+    if (out16) {
+      half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+      *reinterpret_cast<half4*>(out16 + (size_t)orow * D + d) = h;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Attention, one workgroup per (image, head); thread i owns query row i.  K/V (and Q/dO in the
+// backward) are staged in LDS as f16 and read as wave-wide broadcasts; all arithmetic fp32.
+// qkv: [M, 3D] f16 (q | k | v, head h at columns h*64..), att: [M, D] f16, lse: [S*heads*T] f32.
+// ---------------------------------------------------------------------------------
+struct alignas(16) H8 { half2 p[4]; };   // 8 halfs = one 16-byte LDS / global access
+
+__device__ __forceinline__ void load_row64h(const half_t* __restrict__ p, H8 r[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) r[c] = *reinterpret_cast<const H8*>(p + c * 8);
+}
+// fp16 x fp16 dot with fp32 accumulation (v_dot2_f32_f16)
+__device__ __forceinline__ float dot_hh(const H8 a[8], const half_t* __restrict__ b) {
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const H8 t = *reinterpret_cast<const H8*>(b + c * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = dot2_f16(a[c].p[u], t.p[u], acc);
+  }
+  return acc;
+}
+__device__ __forceinline__ void axpy_row64(float acc[64], float w, const half_t* __restrict__ b) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const H8 t = *reinterpret_cast<const H8*>(b + c * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[c * 8 + 2 * u] += w * (float)t.p[u][0];
+      acc[c * 8 + 2 * u + 1] += w * (float)t.p[u][1];
+    }
+  }
+}
+__device__ __forceinline__ void store_row64(half_t* __restrict__ dst, const float v[64], float scale) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    half8 hv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[j] = (half_t)(v[c * 8 + j] * scale);
+    *reinterpret_cast<half8*>(dst + c * 8) = hv;
+  }
+}
+__device__ __forceinline__ void stage_rows(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld, int T) {
+  // T rows x 64 halfs, 16-byte chunks
+  for (int q = threadIdx.x; q < T * 8; q += blockDim.x) {
+    const int r = q >> 3, c = q & 7;
+    *reinterpret_cast<H8*>(dst + r * 64 + c * 8) = *reinterpret_cast<const H8*>(src + (size_t)r * ld + c * 8);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att, float* __restrict__ lse, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vs = Ks + T * 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * kHeadDim, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * kHeadDim;
+  stage_rows(Ks, base + D, ld, T);
+  stage_rows(Vs, base + 2 * D, ld, T);
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= T) return;
+  H8 q[8];
+  float o[64];
+  load_row64h(base + (size_t)i * ld, q);
+#pragma unroll
+  for (int d = 0; d < 64; ++d) o[d] = 0.f;
+  float mx = -1e30f, l = 0.f;
+  for (int j0 = 0; j0 < T; j0 += 8) {
+    float sc[8];
+    float cm = mx;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sc[u] = (j0 + u < T) ? dot_hh(q, Ks + (j0 + u) * 64) * 0.125f : -1e30f;   // head_dim ** -0.5
+      cm = fmaxf(cm, sc[u]);
+    }
+    const float f = __expf(mx - cm);
+    l *= f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] *= f;
+    mx = cm;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < T) {
+        const float p = __expf(sc[u] - mx);
+        l += p;
+        axpy_row64(o, p, Vs + (j0 + u) * 64);
+      }
+    }
+  }
+  store_row64(att + ((size_t)s * T + i) * D + h * kHeadDim, o, 1.0f / l);
+  lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
+}
+
+// backward: dO = datt [M,D] f16 -> dqkv [M,3D] f16.  P is recomputed from q, k and the saved lse.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att, const half_t* __restrict__ datt,
+                                const float* __restrict__ lse, half_t* __restrict__ dqkv, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Qs = reinterpret_cast<half_t*>(smem);
+  half_t* Ks = Qs + T * 64;
+  half_t* Vs = Ks + T * 64;
+  half_t* Os = Vs + T * 64;               // dO
+  float* Ls = reinterpret_cast<float*>(Os + T * 64);
+  float* Ds = Ls + T;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * kHeadDim, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * kHeadDim;
+  const half_t* dob = datt + (size_t)s * T * D + h * kHeadDim;
+  const half_t* ob = att + (size_t)s * T * D + h * kHeadDim;
+  stage_rows(Qs, base, ld, T);
+  stage_rows(Ks, base + D, ld, T);
+  stage_rows(Vs, base + 2 * D, ld, T);
+  stage_rows(Os, dob, D, T);
+  const int i = threadIdx.x;
+  const bool live = i < T;
+  if (live) {
+    H8 o[8];
+    load_row64h(ob + (size_t)i * D, o);
+    Ds[i] = dot_hh(o, dob + (size_t)i * D);          // D_i = dO_i . O_i
+    Ls[i] = lse[((size_t)s * heads + h) * T + i];
+  }
+  __syncthreads();
+  half_t* dbase = dqkv + (size_t)s * T * ld + h * kHeadDim;
+  if (live) {
+    // phase 1 (query rows): dq_i = scale * sum_j p_ij (dP_ij - D_i) k_j
+    H8 q[8], go[8];
+    float dq[64];
+    load_row64h(Qs + i * 64, q);
+    load_row64h(Os + i * 64, go);
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dq[d] = 0.f;
+    const float Li = Ls[i], Di = Ds[i];
+    for (int j = 0; j < T; ++j) {
+      const float p = __expf(dot_hh(q, Ks + j * 64) * 0.125f - Li);
+      const float dp = dot_hh(go, Vs + j * 64);
+      axpy_row64(dq, p * (dp - Di) * 0.125f, Ks + j * 64);
+    }
+    store_row64(dbase + (size_t)i * ld, dq, 1.0f);
+  }
+  if (live) {
+    // phase 2 (key rows, thread j = i): dv_j = sum_i p_ij dO_i ; dk_j = scale * sum_i dS_ij q_i
+    const int j = i;
+    H8 k[8], v[8];
+    float dk[64], dv[64];
+    load_row64h(Ks + j * 64, k);
+    load_row64h(Vs + j * 64, v);
+#pragma unroll
+    for (int d = 0; d < 64; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int r = 0; r < T; ++r) {
+      const float p = __expf(dot_hh(k, Qs + r * 64) * 0.125f - Ls[r]);
+      const float dp = dot_hh(v, Os + r * 64);
+      axpy_row64(dv, p, Os + r * 64);
+      axpy_row64(dk, p * (dp - Ds[r]) * 0.125f, Qs + r * 64);
+    }
+    store_row64(dbase + (size_t)j * ld + D, dk, 1.0f);
+    store_row64(dbase + (size_t)j * ld + 2 * D, dv, 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// head: enc[s] = LN_post(x[s*T + 0]) @ proj        (proj [D, E] f32)
+// ---------------------------------------------------------------------------------
+__global__ void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ proj, float* __restrict__ enc, int T, int D, int E) {
+  APH_DYN_SMEM(smem);
+  float* y = reinterpret_cast<float*>(smem);
+  __shared__ float red[16];
+  const int s = blockIdx.x;
+  const float* row = x + (size_t)s * T * D;
+  float a = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) a += row[d];
+  const float mean = block_sum(a, red) / D;
+  float q = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) { const float c = row[d] - mean; q += c * c; }
+  const float rstd = rsqrtf(block_sum(q, red) / D + kLnEps);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) y[d] = (row[d] - mean) * rstd * gamma[d] + beta[d];
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += y[d] * proj[(size_t)d * E + e];
+    enc[(size_t)s * E + e] = acc;
+  }
+}
+
+// head backward: genc [S,E] -> dx (fp32 [M,D], zero except class rows) and its f16 copy.
+// projT = proj transposed [E, D].
+__global__ void head_bwd_kernel(const float* __restrict__ genc, const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ projT, float* __restrict__ dx, half_t* __restrict__ dx16, int T, int D, int E) {
+  APH_DYN_SMEM(smem);
+  float* ge = reinterpret_cast<float*>(smem);   // [E]
+  float* gy = ge + E;                            // [D]  gamma * dy
+  float* xh = gy + D;                            // [D]  xhat
+  __shared__ float red[16];
+  const int s = blockIdx.x;
+  const float* row = x + (size_t)s * T * D;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) ge[e] = genc[(size_t)s * E + e];
+  float a = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) a += row[d];
+  const float mean = block_sum(a, red) / D;
+  float q = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) { const float c = row[d] - mean; q += c * c; }
+  const float rstd = rsqrtf(block_sum(q, red) / D + kLnEps);
+  float sg = 0.f, sgx = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float acc = 0.f;
+    for (int e = 0; e < E; ++e) acc += ge[e] * projT[(size_t)e * D + d];
+    const float g = acc * gamma[d], xv = (row[d] - mean) * rstd;
+    gy[d] = g; xh[d] = xv;
+    sg += g; sgx += g * xv;
+  }
+  sg = block_sum(sg, red) / D;
+  sgx = block_sum(sgx, red) / D;
+  // class row gets the LN_post input-gradient, all other token rows of this image are zero
+  for (int idx = threadIdx.x; idx < T * D; idx += blockDim.x) {
+    const int t = idx / D, d = idx - t * D;
+    const float v = t == 0 ? rstd * (gy[d] - sg - xh[d] * sgx) : 0.f;
+    dx[(size_t)s * T * D + idx] = v;
+    dx16[(size_t)s * T * D + idx] = (half_t)v;
+  }
+}
+
+}  // namespace aph

@@ -1,0 +1,132 @@
+/* libaphantasia_hip.so -- C ABI of the MI355X (gfx950) hot path of eps696/aphantasia.
+ *
+ * The reference has no FFI layer of its own: its per-step loop (clip_fft.py:235-306) calls
+ * Python functions (aphantasia/image.py, aphantasia/utils.py, aphantasia/transforms.py,
+ * openai/CLIP's model.encode_image, torch.optim.Adam).  Each entry point below replaces one of
+ * those call sites; the ctypes stubs a maintainer would add are in INTEGRATION.md.
+ *
+ * Conventions: plain C types; every pointer named d_* / documented "device" is a HIP device
+ * pointer (tensor.data_ptr()); `stream` is a hipStream_t passed as void* (0 = default stream);
+ * all calls are asynchronous on that stream and never allocate per call; return value 0 = ok,
+ * < 0 = error (message through aph_last_error(), thread-local).
+ */
+#ifndef APHANTASIA_HIP_H
+#define APHANTASIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APH_OK 0
+#define APH_ERR_ARG (-1)
+#define APH_ERR_HIP (-2)
+#define APH_ERR_UNSUPPORTED (-3)
+#define APH_ERR_INTERNAL (-4)
+
+int aph_version(void);
+const char* aph_last_error(void);
+
+/* ---- image parameteriser: aphantasia/image.py ------------------------------------------- */
+typedef struct aph_synth_plan aph_synth_plan;
+
+/* twiddles + workspace for a C x H x W image (fft_image closure state, image.py:152-162) */
+int aph_synth_plan_create(int C, int H, int W, aph_synth_plan** out);
+int aph_synth_plan_destroy(aph_synth_plan* plan);
+
+/* to_valid_rgb(fft_image(...))(shift, contrast): image.py:164-175 + :21-28.
+ * params [C,H,W/2+1,2] f32, scale [H,W/2+1] f32, shift [H,W/2+1] f32 or NULL, colcorr_t9 = 3x3
+ * row-major colcorr_t (image.py:19) host pointer or NULL (identity).  Writes raw [C,H,W] (the
+ * irfft2 output before std-normalisation) and rgb [C,H,W] in (0,1). */
+int aph_synth_fft_fwd(aph_synth_plan* plan, const float* d_params, const float* d_scale, const float* d_shift,
+                      float contrast, const float* colcorr_t9, int decorrelate, float* d_raw, float* d_rgb, void* stream);
+/* adjoint: d_rgb_grad [C,H,W] (multiplied by gscale) -> d_grad_params [C,H,W/2+1,2].  Must follow the
+ * aph_synth_fft_fwd that produced rgb/raw (the plan keeps mean/std). */
+int aph_synth_fft_bwd(aph_synth_plan* plan, const float* d_rgb_grad, float gscale, const float* d_rgb, const float* d_raw,
+                      const float* d_scale, float contrast, const float* colcorr_t9, int decorrelate,
+                      float* d_grad_params, void* stream);
+/* to_valid_rgb(pixel_image(...)) (image.py:114-118) and the post-inverse-DWT part of dwt_image (image.py:68):
+ * raw -> raw*contrast/std (or /fixed_div when fixed_div > 0) -> colour mix -> sigmoid */
+int aph_synth_spatial_fwd(aph_synth_plan* plan, const float* d_raw, float contrast, float fixed_div,
+                          const float* colcorr_t9, int decorrelate, float* d_rgb, void* stream);
+int aph_synth_spatial_bwd(aph_synth_plan* plan, const float* d_rgb_grad, float gscale, const float* d_rgb,
+                          const float* d_raw, float contrast, float fixed_div, const float* colcorr_t9, int decorrelate,
+                          float* d_raw_grad, void* stream);
+/* {mean, std} of raw from the last forward -> d_out2 (device, 2 floats) */
+int aph_synth_stats(aph_synth_plan* plan, float* d_out2, void* stream);
+
+/* ---- sampler: aphantasia/utils.py:218-254 slice_imgs + transforms.py:102-109,165-170 ------- */
+/* Geometry of one slice_imgs call.  (Hp,Wp,py0,px0) describe the wrap-tiled overscan frame of
+ * pad_up_to/tile_pad (utils.py:152-187); Hp=H, Wp=W, py0=px0=0 when align has no 'over'. */
+typedef struct aph_sample_geom {
+  int H, W;          /* source image */
+  int Hp, Wp;        /* padded frame the crop table refers to */
+  int py0, px0;      /* top / left padding */
+  int S;             /* number of cuts */
+  int size;          /* output side (224) */
+  int patch;         /* ViT patch size for the patch-major layouts (32 / 16) */
+} aph_sample_geom;
+
+#define APH_OUT_NCHW_RAW 0   /* f32 [S,3,size,size], no normalisation (transform=None) */
+#define APH_OUT_NCHW_NORM 1  /* f32 [S,3,size,size], CLIP mean/std normalised (transforms.normalize) */
+#define APH_OUT_PATCH_F16 2  /* f16 [S*(size/patch)^2, 3*patch*patch] normalised = patch-embed GEMM operand */
+
+#define APH_AUG_STRIDE 16
+/* per-cut augment row (f32 x 16): [0..7] perspective coeffs, [8] has_perspective, [9..12] erase i,j,h,w
+ * (h=0: none), [13] cos(angle), [14] sin(angle), [15] has_rotation (transforms_fast always 1) */
+
+/* d_rgb [3,H,W] f32; d_table int32 [S,3] rows (csize, offx, offy) (utils.py:245-247);
+ * d_aug f32 [S,16] or NULL (no geometric augmentation); d_tmp: f32 scratch of 2*S*3*size*size
+ * elements, only needed when d_aug != NULL.  out layout per out_mode. */
+int aph_sample_fwd(const aph_sample_geom* g, const float* d_rgb, const int32_t* d_table, const float* d_aug,
+                   float* d_tmp, void* d_out, int out_mode, void* stream);
+/* adjoint.  d_out_grad: f32 in the layout of out_mode (patch-major f32 for APH_OUT_PATCH_F16), multiplied by
+ * gscale.  d_tmp as above (overwritten).
+ * Writes (does not accumulate) d_rgb_grad [3,H,W]. */
+int aph_sample_bwd(const aph_sample_geom* g, const float* d_out_grad, float gscale, const int32_t* d_table,
+                   const float* d_aug, float* d_tmp, float* d_rgb_grad, int out_mode, void* stream);
+/* NCHW f32 [S,3,R,R] <-> patch-major (entry of model.encode_image for a caller-made batch) */
+int aph_patchify_f16(const float* d_nchw, int S, int R, int patch, void* d_patches_f16, void* stream);
+int aph_unpatchify_f32(const float* d_patch_grad, int S, int R, int patch, float gscale, float* d_nchw_grad, void* stream);
+
+/* ---- CLIP ViT visual tower: model.encode_image (clip_fft.py:254) + its input-gradient ----- */
+typedef struct aph_vit aph_vit;
+/* mirrors clip.model.VisionTransformer(input_resolution, patch_size, width, layers, heads, output_dim);
+ * max_batch = largest number of cuts per call (activation arena is sized once, never re-allocated) */
+int aph_vit_create(int input_resolution, int patch_size, int width, int layers, int heads, int output_dim,
+                   int max_batch, aph_vit** out);
+int aph_vit_destroy(aph_vit* vit);
+size_t aph_vit_workspace_bytes(const aph_vit* vit);
+/* one tensor by its OpenAI checkpoint key without the "visual." prefix (fp32 HOST data) */
+int aph_vit_set_weight(aph_vit* vit, const char* name, const float* h_data, size_t count);
+/* d_patches f16 [S*P, 3*patch^2] (APH_OUT_PATCH_F16 layout) -> d_enc f32 [S, output_dim] */
+int aph_vit_forward(aph_vit* vit, const void* d_patches, int S, float* d_enc, void* stream);
+/* d_genc f32 [S, output_dim] (times the caller's loss scale) -> d_patch_grad f32 [S*P, 3*patch^2] times out_scale */
+int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream);
+/* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core, exported for tests */
+int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
+
+/* ---- loss: aphantasia/utils.py:270-295 sim_func, assembled as at clip_fft.py:257-267 -------- */
+#define APH_SIM_COS 0   /* type None / 'cossim' */
+#define APH_SIM_MIX 1   /* 'mix' (default) */
+#define APH_SIM_ANG 2   /* 'ang' */
+#define APH_SIM_DOT 3   /* 'dot' */
+/* loss = sum_t coef_t * sim_func(target_t, enc, type), value -> d_loss (1 float) and
+ * gscale * dloss/denc -> d_genc [S,D].  d_targets [T,D], d_coef [T] (sign*weight), h_coef = host copy
+ * (needed for 'ang'), denom = sample count of the global mean (S, or the all-rank total),
+ * d_ws = f32 scratch of S*(T+2) elements. */
+int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const float* d_coef, const float* h_coef,
+                 int T, int type, float denom, float gscale, float* d_ws, float* d_loss, float* d_genc, void* stream);
+
+/* ---- optimiser: torch.optim.Adam / AdamW as configured at clip_fft.py:108-115 --------------- */
+/* d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale};
+ * d_m may be NULL when beta1 == 0, d_vmax NULL unless amsgrad; decoupled_wd = AdamW */
+int aph_adam_step(float* d_p, const float* d_g, float* d_m, float* d_v, float* d_vmax, const float* d_hyper,
+                  int decoupled_wd, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
