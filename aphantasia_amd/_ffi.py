@@ -30,6 +30,7 @@ _PROTOTYPES = {
     'aph_synth_spatial_fwd': (c_int, [c_void_p, c_void_p, c_float, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_synth_spatial_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_synth_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'aph_synth_set_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
     'aph_sample_fwd': (c_int, [POINTER(SampleGeom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_sample_bwd': (c_int, [POINTER(SampleGeom), c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_patchify_f16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -40,6 +41,8 @@ _PROTOTYPES = {
     'aph_vit_set_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     'aph_vit_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_vit_backward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p]),
+    'aph_vit_profile': (c_int, [c_void_p, c_int]),
+    'aph_vit_profile_read': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_sim_loss': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
@@ -82,6 +85,12 @@ def lib():
     """The product library (loaded once)."""
     global _lib
     if _lib is None:
+        import torch
+        if torch.cuda.is_available():
+            # one HIP runtime per process: torch's is already loaded; let it create the primary context and
+            # the caching allocator's device state before the library makes its first hipMalloc
+            torch.cuda.init()
+            torch.empty(1, device='cuda')
         _lib = Library(LIB_PATH)
     return _lib
 

@@ -552,4 +552,14 @@ int aph_synth_stats(aph_synth_plan* p, float* out2, void* stream_) {
   APH_CATCH
 }
 
+// restores {mean, std} saved by aph_synth_stats (an autograd node whose forward was followed by other forwards)
+int aph_synth_set_stats(aph_synth_plan* p, const float* in2, void* stream_) {
+  APH_TRY
+  if (!p || !in2) return aph_fail(APH_ERR_ARG, "aph_synth_set_stats: null argument");
+  if (hipMemcpyAsync(p->stats, in2, 2 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_) != hipSuccess)
+    return aph_fail(APH_ERR_HIP, "aph_synth_set_stats: copy failed");
+  return APH_OK;
+  APH_CATCH
+}
+
 }  // extern "C"

@@ -42,6 +42,11 @@ struct aph_vit {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int n_set = 0;
+  // optional per-launch timing of the GEMM family (bench.py roofline): HIP event pairs on the launch stream
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;     // pairs
+  size_t prof_used = 0;
+  double prof_flops = 0.0;
 };
 
 namespace {
@@ -100,6 +105,21 @@ int upload_f32(float* dst, const float* src, size_t rows, size_t cols, bool tran
   return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 
+template <class Epi>
+void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+  if (!v->prof_on) { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st); return; }
+  if (v->prof_used + 2 > v->prof_ev.size()) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    v->prof_ev.push_back(a); v->prof_ev.push_back(b);
+  }
+  (void)hipEventRecord(v->prof_ev[v->prof_used], st);
+  launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st);
+  (void)hipEventRecord(v->prof_ev[v->prof_used + 1], st);
+  v->prof_used += 2;
+  v->prof_flops += 2.0 * M * N * K;
+}
+
 template <bool OUT_F16, bool CLS>
 void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void* out, int M, int T, const float* cls,
                    const float* pos, float* x_fill, hipStream_t st) {
@@ -144,7 +164,8 @@ int aph_vit_create(int input_resolution, int patch_size, int width, int layers, 
   v->layers.resize(layers);
   size_t total = 0;
   carve(v, nullptr, &total);
-  if (hipMalloc((void**)&v->arena, total) != hipSuccess) { delete v; return aph_fail(APH_ERR_HIP, "aph_vit_create: cannot allocate %zu bytes", total); }
+  const hipError_t me = hipMalloc((void**)&v->arena, total);
+  if (me != hipSuccess) { delete v; return aph_fail(APH_ERR_HIP, "aph_vit_create: cannot allocate %zu bytes (%s)", total, hipGetErrorString(me)); }
   v->arena_bytes = total;
   carve(v, v->arena, &total);
   const size_t bwd_smem = (size_t)4 * v->T * 128 + 8 * v->T;
@@ -217,18 +238,18 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
   if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_forward: weights not fully loaded (%d tensors)", v->n_set);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
-  launch_gemm((const half_t*)d_patches, v->Kp, v->w_patch, v->Kp, S * v->P, D, v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
+  vgemm(v, (const half_t*)d_patches, v->Kp, v->w_patch, v->Kp, S * v->P, D, v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
   launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st);
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
     launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
-    launch_gemm(v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+    vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
     APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
-    launch_gemm(l.att, D, l.w_o, D, M, D, D, EpiResidual{l.x_mid, l.x_in, D, l.b_o}, st);
+    vgemm(v, l.att, D, l.w_o, D, M, D, D, EpiResidual{l.x_mid, l.x_in, D, l.b_o}, st);
     launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, M, T, nullptr, nullptr, nullptr, st);
-    launch_gemm(v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
-    launch_gemm(v->gact, 4 * D, l.w_fc2, 4 * D, M, D, 4 * D, EpiResidual{x_next, l.x_mid, D, l.b_fc2}, st);
+    vgemm(v, v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
+    vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, M, D, 4 * D, EpiResidual{x_next, l.x_mid, D, l.b_fc2}, st);
   }
   APH_LAUNCH(head_fwd_kernel, dim3(S), dim3(256), sizeof(float) * D, st, (const float*)v->x_last, (const float*)v->ln_post_g,
              (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
@@ -248,18 +269,43 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];
-    launch_gemm(v->dx16, D, l.w_fc2T, D, M, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
-    launch_gemm(v->du, 4 * D, l.w_fc1T, 4 * D, M, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
+    vgemm(v, v->dx16, D, l.w_fc2T, D, M, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+    vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, M, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, M, T, st);
-    launch_gemm(v->dx16, D, l.w_oT, D, M, D, D, EpiF16{v->datt, D, nullptr}, st);
+    vgemm(v, v->dx16, D, l.w_oT, D, M, D, D, EpiF16{v->datt, D, nullptr}, st);
     APH_LAUNCH(attn_bwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)4 * T * 128 + 8 * T, st, (const half_t*)l.qkv,
                (const half_t*)l.att, (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
-    launch_gemm(v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
+    vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
   }
   launch_ln_bwd<false, true>(nv, v->dx, v->x0, v->ln_pre_g, nullptr, nullptr, v->dx0_16, M, T, st);
-  launch_gemm(v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{d_patch_grad, v->Kp, out_scale}, st);
+  vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{d_patch_grad, v->Kp, out_scale}, st);
   return aph_check_launch("aph_vit_backward");
+  APH_CATCH
+}
+
+// GEMM-family timing for bench.py: enable, run steps, then read {sum of launch durations [ms], launches, flops}
+int aph_vit_profile(aph_vit* v, int on) {
+  APH_TRY
+  if (!v) return aph_fail(APH_ERR_ARG, "aph_vit_profile: null handle");
+  v->prof_on = on != 0;
+  v->prof_used = 0;
+  v->prof_flops = 0.0;
+  return APH_OK;
+  APH_CATCH
+}
+int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, double* flops) {
+  APH_TRY
+  if (!v || !ms_total || !launches || !flops) return aph_fail(APH_ERR_ARG, "aph_vit_profile_read: null argument");
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < v->prof_used; i += 2) {
+    if (hipEventSynchronize(v->prof_ev[i + 1]) != hipSuccess) return aph_fail(APH_ERR_HIP, "aph_vit_profile_read: event sync failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, v->prof_ev[i], v->prof_ev[i + 1]) != hipSuccess) return aph_fail(APH_ERR_HIP, "aph_vit_profile_read: elapsed failed");
+    total += ms;
+  }
+  *ms_total = total; *launches = (long long)(v->prof_used / 2); *flops = v->prof_flops;
+  return APH_OK;
   APH_CATCH
 }
 

@@ -1,0 +1,176 @@
+"""The fused optimisation step: clip_fft.py's train(i) (clip_fft.py:235-295) as one chain of C-ABI
+calls on a HIP stream -- no autograd graph, no per-step allocation, no host synchronisation.
+
+    synth (irfft2 .. sigmoid) -> sampler (S cuts, patch-major f16) -> ViT forward -> similarity loss
+      -> ViT input-gradient -> sampler adjoint -> synth adjoint (rfft2) -> [all-reduce] -> Adam
+
+The autograd-based drop-in API (image.py / utils.py / clip.py) calls the same C entry points; this
+class is what clip_fft.py and bench.py run when the loss is the standard prompt/image similarity sum.
+
+Multi-GPU: every rank holds the full parameters, draws the SAME crop table,
+processes a contiguous share of the S cuts, and the spectrum gradients are summed with ONE
+all-reduce (RCCL through torch.distributed) per step; the loss term of each rank is already divided
+by the global S, so the sum of the partial gradients is the single-GPU gradient.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _ffi, ops
+from .clip import LOSS_SCALE
+from .image import colcorr_t, fft_scale
+from .transforms import Transform, pack_aug
+from .utils import draw_crop_params
+
+
+def shard_range(S, rank, world):
+    """Contiguous share of S cuts for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(S, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Engine:
+    def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
+                 lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
+                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None):
+        """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel');
+        model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
+        coef = sign*weight as at clip_fft.py:257-267."""
+        self.params = params
+        self.dev = params.device
+        self.h, self.w = h, w
+        self.kind = param_kind
+        self.model = model
+        self.visual = model.visual
+        self.size = size or self.visual.input_resolution
+        self.patch = self.visual.patch_size
+        self.S = int(samples)
+        self.rank, self.world, self.pg = rank, world, process_group
+        self.lo, self.hi = shard_range(self.S, rank, world)
+        self.S_loc = self.hi - self.lo
+        self.sim = sim
+        self.align, self.macro, self.transform = align, macro, transform
+        self.cc = colcorr_t(colors).flatten().tolist()
+        self.decorrelate = decorrelate
+        self.lib = lib if lib is not None else _ffi.lib()
+        self.plan = ops.SynthPlan(3, h, w, lib=self.lib)
+        self.scale = fft_scale(h, w, decay).to(self.dev).contiguous() if param_kind == 'fft' else None
+        self.lr = lr
+        name = optimizer.lower()
+        self.beta1 = 0.9 if name in ('adam', 'adamw') else 0.0
+        self.wd = 0.01 if name.startswith('adamw') else 0.0
+        self.decoupled = name.startswith('adamw')
+        self.amsgrad = name == 'adamw_custom'
+        n = params.numel()
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.m = torch.zeros(n, **f32) if self.beta1 else None
+        self.v = torch.zeros(n, **f32)
+        self.vmax = torch.zeros(n, **f32) if self.amsgrad else None
+        self.step_count = 0
+        self.set_targets(targets)
+        # static buffers
+        self.visual.ensure_batch(max(self.S_loc, 1))
+        g = self.size // self.patch
+        self.P, self.Kp = g * g, 3 * self.patch * self.patch
+        D = self.visual.output_dim
+        Sl = max(self.S_loc, 1)
+        self.raw = torch.empty(3, h, w, **f32)
+        self.rgb = torch.empty(3, h, w, **f32)
+        self.patches = torch.empty(Sl * self.P, self.Kp, dtype=torch.float16, device=self.dev)
+        self.gpatch = torch.empty(Sl * self.P, self.Kp, **f32)
+        self.enc = torch.empty(Sl, D, **f32)
+        self.genc = torch.empty(Sl, D, **f32)
+        self.grgb = torch.empty(3, h, w, **f32)
+        self.grad = torch.empty_like(params)
+        self.loss = torch.zeros(1, **f32)
+        self.ws = torch.empty(Sl * (len(targets) + 2), **f32)
+        self.hyper = torch.empty(8, **f32)
+        self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
+        self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
+        self.geometric = isinstance(transform, Transform) and transform.geometric
+        self.aug = torch.empty(Sl, _ffi.APH_AUG_STRIDE, **f32) if self.geometric else None
+        self.tmp = torch.empty(2 * Sl * 3 * self.size * self.size, **f32) if self.geometric else None
+
+    def set_targets(self, targets):
+        self.targets = torch.cat([t.reshape(1, -1).float() for t, _ in targets], 0).to(self.dev).contiguous()
+        self.coef = [float(c) for _, c in targets]
+        self.dcoef = torch.tensor(self.coef, dtype=torch.float32, device=self.dev)
+        self.hcoef = _ffi.floats(self.coef)
+
+    # ------------------------------------------------------------------
+    def draw(self):
+        """Host-side random draws for one step (the reference's own order, utils.py:222-251)."""
+        return draw_crop_params(self.S, self.size, self.h, self.w, self.align, self.macro, self.transform)
+
+    def synthesize(self, contrast=1.0, shift=None):
+        """image_f(shift, contrast) under no_grad (clip_fft.py:239 / :299) -> rgb [3,h,w] (engine-owned buffer)."""
+        L, st = self.lib, ops._stream(self.params)
+        if self.kind == 'fft':
+            L.call('aph_synth_fft_fwd', self.plan.handle, ops.ptr(self.params), ops.ptr(self.scale), ops.ptr(shift), float(contrast),
+                   _ffi.floats(self.cc), int(self.decorrelate), ops.ptr(self.raw), ops.ptr(self.rgb), st)
+        else:
+            L.call('aph_synth_spatial_fwd', self.plan.handle, ops.ptr(self.params), float(contrast), 0.0, _ffi.floats(self.cc),
+                   int(self.decorrelate), ops.ptr(self.rgb), st)
+        return self.rgb
+
+    def step(self, table=None, augs=None, lr=None, shift=None):
+        """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
+        if table is None:
+            table, augs = self.draw()
+        L, st = self.lib, ops._stream(self.params)
+        Sl = self.S_loc
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        hy = ops.adam_hyper(self.step_count, lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
+        self.hyper.copy_(torch.tensor(hy, dtype=torch.float32), non_blocking=True)
+        if Sl > 0:
+            self.table.copy_(torch.from_numpy(np.ascontiguousarray(table[self.lo:self.hi])), non_blocking=True)
+            if self.geometric:
+                self.aug.copy_(pack_aug(augs[self.lo:self.hi]), non_blocking=True)
+        # forward
+        self.synthesize(1.0, shift)
+        cc = _ffi.floats(self.cc)
+        if Sl > 0:
+            L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table), ops.ptr(self.aug), ops.ptr(self.tmp),
+                   ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
+            self.visual._forward_patches(self.patches, Sl, self.enc)
+            L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
+                   len(self.coef), _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
+                   ops.ptr(self.loss), ops.ptr(self.genc), st)
+            # backward
+            self.visual.handle.backward(self.genc, Sl, self.gpatch, 1.0 / LOSS_SCALE)
+            L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), 1.0, ops.ptr(self.table), ops.ptr(self.aug),
+                   ops.ptr(self.tmp), ops.ptr(self.grgb), _ffi.APH_OUT_PATCH_F16, st)
+        else:
+            self.grgb.zero_()
+            self.loss.zero_()
+        if self.kind == 'fft':
+            L.call('aph_synth_fft_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.raw), ops.ptr(self.scale),
+                   1.0, cc, int(self.decorrelate), ops.ptr(self.grad), st)
+        else:
+            L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, 0.0, cc,
+                   int(self.decorrelate), ops.ptr(self.grad), st)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
+        L.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
+               ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), st)
+        return self.loss
+
+    def global_loss(self):
+        """The step's loss summed over ranks (host float; synchronises)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            t = self.loss.clone()
+            if self.sim and 'ang' in str(self.sim) and self.rank != 0:
+                t -= sum(self.coef)          # the constant of 'ang' is counted once
+            dist.all_reduce(t, group=self.pg)
+            return float(t)
+        return float(self.loss)
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)

@@ -56,6 +56,8 @@ int aph_synth_spatial_bwd(aph_synth_plan* plan, const float* d_rgb_grad, float g
                           float* d_raw_grad, void* stream);
 /* {mean, std} of raw from the last forward -> d_out2 (device, 2 floats) */
 int aph_synth_stats(aph_synth_plan* plan, float* d_out2, void* stream);
+/* restore them (d_in2 device, 2 floats) before an adjoint whose forward was followed by other forwards */
+int aph_synth_set_stats(aph_synth_plan* plan, const float* d_in2, void* stream);
 
 /* ---- sampler: aphantasia/utils.py:218-254 slice_imgs + transforms.py:102-109,165-170 ------- */
 /* Geometry of one slice_imgs call.  (Hp,Wp,py0,px0) describe the wrap-tiled overscan frame of
@@ -105,6 +107,9 @@ int aph_vit_set_weight(aph_vit* vit, const char* name, const float* h_data, size
 int aph_vit_forward(aph_vit* vit, const void* d_patches, int S, float* d_enc, void* stream);
 /* d_genc f32 [S, output_dim] (times the caller's loss scale) -> d_patch_grad f32 [S*P, 3*patch^2] times out_scale */
 int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream);
+/* per-launch HIP-event timing of the ViT's GEMM launches (bench.py roofline): on/off, then read the sums */
+int aph_vit_profile(aph_vit* vit, int on);
+int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
 /* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core, exported for tests */
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
 

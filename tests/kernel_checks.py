@@ -1,0 +1,197 @@
+"""Kernel checks shared by the CPU (tests/emu interpreter) and GPU (libaphantasia_hip.so) test files.
+Each check drives the C ABI through aphantasia_amd.ops on tensors living on `dev` and compares with the
+oracle (oracle/) or the reference-generated goldens.  lib=None selects the product library."""
+import numpy as np
+import torch
+
+from aphantasia_amd import _ffi, ops
+from aphantasia_amd.transforms import pack_aug
+from aphantasia_amd.weights import synthetic_visual_weights
+from oracle import reference_path as R
+from oracle import clip_vit_ref, augment_ref
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def to_patch_major(x, p):
+    """[S,3,R,R] -> [S*g*g, 3*p*p] (the APH_OUT_PATCH_F16 element order)"""
+    S, _, Rr, _ = x.shape
+    g = Rr // p
+    return x.reshape(S, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(S * g * g, 3 * p * p)
+
+
+def check_synth_golden(lib, dev, g):
+    h, w = int(g['h']), int(g['w'])
+    params = torch.from_numpy(g['params']).to(dev).contiguous()
+    scale = R.fft_scale(h, w, float(g['decay'])).to(dev).contiguous()
+    cc = R.colcorr_t(float(g['colors'])).flatten().tolist()
+    plan = ops.SynthPlan(3, h, w, lib=lib)
+    contrast = float(g['contrast'])
+    raw, rgb = ops.synth_fft_fwd(plan, params, scale, None, contrast, cc, True, lib=lib)
+    raw_c, rgb_c = raw.cpu(), rgb.cpu()
+    assert np.allclose((raw_c / raw_c.std()).numpy(), g['raw'][0], atol=2e-5)
+    assert np.allclose(rgb_c.numpy(), g['rgb'][0], atol=2e-6)
+    grad = ops.synth_fft_bwd(plan, torch.from_numpy(g['gw'][0]).to(dev).contiguous(), rgb, raw, scale, contrast, cc, True, lib=lib)
+    ref = g['grad'][0]
+    assert np.abs(grad.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def check_synth_vs_oracle(lib, dev, h, w, contrast=1.0, with_shift=False):
+    """forward + adjoint at an arbitrary size against the torch-CPU oracle (autograd)."""
+    seed_all(1)
+    params = R.fft_params_init([1, 3, h, w]).requires_grad_(True)
+    scale = R.fft_scale(h, w, 1.5)
+    cc_t = R.colcorr_t(1.8)
+    shift = 0.02 * torch.rand(1, 1, h, w // 2 + 1, 1) if with_shift else None
+    want = R.synth_fft(params, scale, h, w, cc_t, contrast, shift)
+    gw = torch.randn(1, 3, h, w)
+    (want * gw).sum().backward()
+    plan = ops.SynthPlan(3, h, w, lib=lib)
+    sh = shift.reshape(h, w // 2 + 1).to(dev).contiguous() if with_shift else None
+    raw, rgb = ops.synth_fft_fwd(plan, params.detach().to(dev).contiguous(), scale.to(dev), sh, contrast,
+                                 cc_t.flatten().tolist(), True, lib=lib)
+    assert (rgb.cpu() - want.detach()[0]).abs().max().item() < 4e-6
+    grad = ops.synth_fft_bwd(plan, gw[0].to(dev).contiguous(), rgb, raw, scale.to(dev), contrast, cc_t.flatten().tolist(), True, lib=lib)
+    ref = params.grad[0]
+    assert (grad.cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+def check_synth_spatial(lib, dev, h=24, w=40):
+    seed_all(2)
+    cc_t = R.colcorr_t(1.8)
+    plan = ops.SynthPlan(3, h, w, lib=lib)
+    for fix in (False, True):
+        img = torch.randn(1, 3, h, w).requires_grad_(True)
+        want = R.synth_pixel(img, cc_t, 1.1, fix)
+        gw = torch.randn(1, 3, h, w)
+        (want * gw).sum().backward()
+        raw = img.detach()[0].to(dev).contiguous()
+        rgb = ops.synth_spatial_fwd(plan, raw, 1.1, 3.3 if fix else 0.0, cc_t.flatten().tolist(), True, lib=lib)
+        assert (rgb.cpu() - want.detach()[0]).abs().max().item() < 2e-6
+        d = ops.synth_spatial_bwd(plan, gw[0].to(dev).contiguous(), rgb, raw, 1.1, 3.3 if fix else 0.0,
+                                  cc_t.flatten().tolist(), True, lib=lib)
+        assert (d.cpu() - img.grad[0]).abs().max().item() < 2e-5 * img.grad.abs().max().item() + 1e-7
+
+
+def check_sampler_golden(lib, dev, g, align):
+    img = torch.from_numpy(g['img'])
+    seed_all(7)
+    table = R.draw_crop_table(6, 16, 48, 80, align, 0.4)
+    geom = ops.make_geom(48, 80, 6, 16, patch=8, align=align)
+    tb = torch.from_numpy(table).to(dev)
+    out = ops.sample_fwd(geom, img[0].to(dev).contiguous(), tb, lib=lib)
+    err = np.abs(out.cpu().numpy() - g['cuts_' + align]).max()
+    assert err < 3e-5, err        # normalised values reach +-2; fp32 contraction order differs from ATen's
+    pm = ops.sample_fwd(geom, img[0].to(dev).contiguous(), tb, out_mode=_ffi.APH_OUT_PATCH_F16, lib=lib)
+    pm2 = ops.patchify(out, 8, lib=lib)
+    assert torch.equal(pm, pm2)
+    assert torch.equal(pm2.cpu(), to_patch_major(out.cpu(), 8).half())
+
+
+def check_sampler_adjoint(lib, dev, align, mode, H=40, W=56, S=5, size=16, patch=8):
+    seed_all(3)
+    img = torch.rand(1, 3, H, W).requires_grad_(True)
+    table = R.draw_crop_table(S, size, H, W, align, 0.4)
+    if min(H, W) > size + 3:
+        table[0] = (size - 3, 1, 2)          # one up-sampling cut (csize < size)
+    cuts = R.slice_imgs(img, table, size, align, transform=None if mode == _ffi.APH_OUT_NCHW_RAW else R.normalize)
+    gout = torch.randn_like(cuts)
+    (cuts * gout).sum().backward()
+    geom = ops.make_geom(H, W, S, size, patch=patch, align=align)
+    gin = to_patch_major(gout, patch) if mode == _ffi.APH_OUT_PATCH_F16 else gout
+    got = ops.sample_bwd(geom, gin.to(dev).contiguous(), torch.from_numpy(table).to(dev), out_mode=mode, gscale=2.0, lib=lib)
+    assert (got.cpu() - 2.0 * img.grad[0]).abs().max().item() < 1e-4 * img.grad.abs().max().item()
+
+
+def check_sampler_augment(lib, dev, H=40, W=48, S=6, size=16, patch=8):
+    seed_all(5)
+    img = torch.rand(1, 3, H, W).requires_grad_(True)
+    prms = []
+    table = R.draw_crop_table(S, size, H, W, 'uniform', 0.4)
+    angles = [-30.0, 0.0, 17.0, 29.0, -5.0, 0.0]
+    for s in range(S):
+        sp, ep = augment_ref.perspective_get_params(size, size, 0.33)
+        prms.append(dict(persp=augment_ref.perspective_coeffs(sp, ep) if s % 2 == 0 else None,
+                         erase=(2, 3, size // 3, size // 2) if s % 6 in (1, 2) else None, angle=angles[s % 6]))
+    cuts = R.slice_imgs(img, table, size, 'uniform', per_cut=lambda c, cut: augment_ref.apply_fast(cut, prms[c], R.normalize))
+    gout = torch.randn_like(cuts)
+    (cuts * gout).sum().backward()
+    aug = pack_aug(prms).to(dev)
+    geom = ops.make_geom(H, W, S, size, patch=patch)
+    tb = torch.from_numpy(table).to(dev)
+    out = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=aug, lib=lib)
+    assert (out.cpu() - cuts.detach()).abs().max().item() < 3e-4
+    got = ops.sample_bwd(geom, gout.to(dev).contiguous(), tb, aug=aug, lib=lib)
+    assert (got.cpu() - img.grad[0]).abs().max().item() < 3e-4 * img.grad.abs().max().item()
+
+
+def check_sim_loss(lib, dev, g):
+    v1 = torch.from_numpy(g['v1'])
+    v2 = torch.from_numpy(g['v2']).contiguous()
+    for t in [None, 'mix', 'ang', 'dot']:
+        loss, genc = ops.sim_loss(v2.to(dev), v1.to(dev).contiguous(), [1.0], t, lib=lib)
+        assert abs(loss.item() - float(g['val_%s' % t])) < 2e-6 * max(1.0, abs(float(g['val_%s' % t]))), t
+        assert np.allclose(genc.cpu().numpy(), g['grad_%s' % t], rtol=2e-4, atol=2e-7), t
+    tg = torch.randn(2, 64, generator=torch.Generator().manual_seed(4))
+    x = v2.clone().requires_grad_(True)
+    want = -1.0 * R.sim_func(tg[0:1], x, 'mix') + 0.5 * R.sim_func(tg[1:2], x, 'mix')
+    want.backward()
+    loss, genc = ops.sim_loss(v2.to(dev), tg.to(dev), [-1.0, 0.5], 'mix', gscale=8.0, lib=lib)
+    assert abs(loss.item() - want.item()) < 1e-6
+    assert np.allclose(genc.cpu().numpy() / 8.0, x.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
+def check_adam(lib, dev, n=5000):
+    gen = torch.Generator().manual_seed(0)
+    for name, kw, dec, ams in [('adam_custom', dict(beta1=0.0), False, False), ('adam', dict(beta1=0.9), False, False),
+                               ('adamw', dict(beta1=0.9, weight_decay=0.01), True, False),
+                               ('adamw_custom', dict(beta1=0.0, weight_decay=0.01), True, True)]:
+        p0 = torch.randn(n, generator=gen)
+        q = p0.clone().requires_grad_(True)
+        p = p0.to(dev)
+        opt = R.make_optimizer([q], name, 0.05)
+        m = torch.zeros(n, device=dev) if kw['beta1'] else None
+        v, vm = torch.zeros(n, device=dev), (torch.zeros(n, device=dev) if ams else None)
+        for step in range(1, 4):
+            grad = torch.randn(n, generator=gen) * 0.01
+            q.grad = grad.clone()
+            opt.step()
+            hyper = torch.tensor(ops.adam_hyper(step, 0.05, **kw), dtype=torch.float32).to(dev)
+            ops.adam_step(p, grad.to(dev), m, v, vm, hyper, dec, lib=lib)
+            assert (p.cpu() - q.detach()).abs().max().item() < 2e-6, name
+
+
+def check_gemm(lib, dev, shapes):
+    gen = torch.Generator().manual_seed(0)
+    for (M, Nn, K) in shapes:
+        A = torch.randn(M, K, generator=gen).half()
+        Bt = torch.randn(Nn, K, generator=gen).half()       # asymmetric operands (catches transposes)
+        C = ops.gemm_f16(A.to(dev), Bt.to(dev), lib=lib)
+        want = A.float() @ Bt.float().T
+        assert (C.cpu() - want).abs().max().item() < 2e-3 * (K / 64) ** 0.5, (M, Nn, K)
+
+
+TINY = dict(input_resolution=32, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
+
+
+def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2):
+    w = synthetic_visual_weights(cfg, 3)
+    Rr, p = cfg['input_resolution'], cfg['patch_size']
+    x = torch.randn(S, 3, Rr, Rr, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    want = clip_vit_ref.encode_image(w, x, cfg)
+    genc = torch.randn(S, cfg['output_dim'], generator=torch.Generator().manual_seed(2)) * 0.01
+    (want * genc).sum().backward()
+    vit = ops.VitHandle(cfg, w, max_batch=S + 1, lib=lib)
+    patches = ops.patchify(x.detach().to(dev).contiguous(), p, lib=lib)
+    enc = vit.forward(patches, S)
+    ferr = (enc.cpu() - want.detach()).abs().max().item() / want.abs().max().item()
+    assert ferr < fwd_tol, ferr
+    LS = 1024.0
+    gp = vit.backward((genc * LS).to(dev).contiguous(), S, out_scale=1.0 / LS)
+    gx = ops.unpatchify(gp, S, Rr, p, lib=lib)
+    berr = (gx.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert berr < bwd_tol, berr
+    return ferr, berr

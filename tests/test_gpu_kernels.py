@@ -1,0 +1,74 @@
+"""GPU (MI355X): every kernel of libaphantasia_hip.so through the C ABI against the oracle and the
+reference-generated goldens, at the golden sizes and at BASELINE.json's full sizes."""
+import pytest
+import torch
+
+from aphantasia_amd import _ffi
+import kernel_checks as K
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('name', ['synth_48x80.npz', 'synth_45x63.npz'])
+def test_synth_golden(golden, name):
+    K.check_synth_golden(None, DEV, golden(name))
+
+
+def test_synth_oracle_small():
+    K.check_synth_vs_oracle(None, DEV, 24, 40, 1.0, with_shift=True)
+    K.check_synth_vs_oracle(None, DEV, 21, 26, 1.1)
+
+
+def test_synth_oracle_full_size():
+    K.check_synth_vs_oracle(None, DEV, 720, 1280, 1.0)
+
+
+def test_synth_spatial():
+    K.check_synth_spatial(None, DEV)
+    K.check_synth_spatial(None, DEV, 720, 1280)
+
+
+@pytest.mark.parametrize('align', ['uniform', 'overscan', 'overmax'])
+def test_sampler_golden(golden, align):
+    K.check_sampler_golden(None, DEV, golden('slice_48x80.npz'), align)
+
+
+@pytest.mark.parametrize('align,mode', [('uniform', _ffi.APH_OUT_NCHW_NORM), ('overscan', _ffi.APH_OUT_NCHW_RAW),
+                                        ('uniform', _ffi.APH_OUT_PATCH_F16)])
+def test_sampler_adjoint(align, mode):
+    K.check_sampler_adjoint(None, DEV, align, mode)
+
+
+def test_sampler_adjoint_full_size():
+    K.check_sampler_adjoint(None, DEV, 'uniform', _ffi.APH_OUT_PATCH_F16, H=720, W=1280, S=12, size=224, patch=32)
+    K.check_sampler_adjoint(None, DEV, 'overscan', _ffi.APH_OUT_NCHW_NORM, H=360, W=640, S=6, size=224, patch=32)
+
+
+def test_sampler_augment():
+    K.check_sampler_augment(None, DEV)
+    K.check_sampler_augment(None, DEV, H=360, W=640, S=12, size=224, patch=32)
+
+
+def test_sim_loss(golden):
+    K.check_sim_loss(None, DEV, golden('sim.npz'))
+
+
+def test_adam():
+    K.check_adam(None, DEV)
+    K.check_adam(None, DEV, n=2769120)
+
+
+def test_gemm_mfma_layout():
+    K.check_gemm(None, DEV, [(100, 128, 64), (130, 256, 192), (9500, 768, 768), (1000, 3072, 768), (777, 768, 3072)])
+
+
+def test_vit_tiny():
+    K.check_vit(None, DEV)
+
+
+@pytest.mark.parametrize('name', ['ViT-B/32', 'ViT-B/16'])
+def test_vit_base(name):
+    from aphantasia_amd.weights import visual_config
+    ferr, berr = K.check_vit(None, DEV, visual_config(name), S=3, fwd_tol=5e-3, bwd_tol=3e-2)
+    print('%s fwd rel err %.2e  bwd rel err %.2e' % (name, ferr, berr))

@@ -1,0 +1,163 @@
+"""GPU (MI355X): the whole optimisation step through the product library -- drop-in autograd API,
+fused engine, loss-curve parity with the oracle, and size-independent properties at BASELINE's sizes."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from aphantasia_amd import _ffi, ops
+from oracle import reference_path as R
+from oracle import clip_vit_ref
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+@pytest.fixture(scope='module')
+def model():
+    from aphantasia_amd import clip as aclip
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m, _ = aclip.load('ViT-B/32', seed=1, max_batch=16)
+    return m
+
+
+def oracle_run(model, h, w, target, params0, **kw):
+    cfg, wts = model.visual.cfg, model.visual.weights
+    return R.ReferenceRun(h, w, lambda x: clip_vit_ref.encode_image(wts, x, cfg), [(target, 1.0)], params=params0, **kw)
+
+
+def test_dropin_api_one_step_vs_oracle(model):
+    """reference-style user code: fft_image / to_valid_rgb / slice_imgs / encode_image / sim_func / torch.optim.Adam"""
+    from aphantasia_amd.image import fft_image, to_valid_rgb
+    from aphantasia_amd.utils import slice_imgs, sim_func
+    from aphantasia_amd import transforms
+    h, w, S = 256, 320, 4
+    seed_all(0)
+    params, image_f, _ = fft_image([1, 3, h, w], 0.07, 1.5, None)
+    rgb_f = to_valid_rgb(image_f, colors=1.8)
+    opt = torch.optim.Adam(params, 0.05, betas=(.0, .999))
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    run = oracle_run(model, h, w, target, params[0].detach().cpu())
+    seed_all(5)
+    img = rgb_f()
+    cuts = slice_imgs([img], S, 224, transforms.normalize(), 'uniform', 0.4)[0]
+    enc = model.encode_image(cuts)
+    loss = -1.0 * sim_func(target.to(DEV), enc, 'mix')
+    opt.zero_grad()
+    loss.backward()
+    grad = params[0].grad.detach().cpu().clone()
+    opt.step()
+    seed_all(5)
+    table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+    want = run.step(table)
+    assert abs(float(loss) - want) < 5e-4
+    ref = run.params.grad
+    assert (grad - ref).abs().max().item() < 5e-2 * ref.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(grad.flatten(), ref.flatten(), dim=0).item()
+    assert cos > 0.999, cos
+    # saved-frame path: image_f(contrast=1.1) under no_grad (clip_fft.py:299)
+    with torch.no_grad():
+        out = rgb_f(contrast=1.1).cpu()
+        wantimg = run.image(1.1)
+    assert (out - wantimg).abs().max().item() < 0.1 and (out - wantimg).pow(2).mean().sqrt().item() < 5e-3
+
+
+def test_plain_image_f_and_pixel_image_grads():
+    from aphantasia_amd.image import fft_image, pixel_image, to_valid_rgb
+    h, w = 48, 64
+    seed_all(1)
+    params, image_f, _ = fft_image([1, 3, h, w], 0.07, 1.5, None)
+    gw = torch.randn(1, 3, h, w)
+    (image_f(contrast=1.2) * gw.to(DEV)).sum().backward()
+    p = params[0].detach().cpu().requires_grad_(True)
+    want = R.std_normalise(R.fft_image_raw(p, R.fft_scale(h, w, 1.5), h, w), 1.2)
+    (want * gw).sum().backward()
+    assert (params[0].grad.cpu() - p.grad).abs().max().item() < 1e-4 * p.grad.abs().max().item()
+    prm, pix_f, _ = pixel_image([1, 3, h, w], sd=1.0)
+    rgb_f = to_valid_rgb(pix_f, colors=2.0)
+    (rgb_f(contrast=0.9) * gw.to(DEV)).sum().backward()
+    q = prm[0].detach().cpu().requires_grad_(True)
+    (R.synth_pixel(q, R.colcorr_t(2.0), 0.9) * gw).sum().backward()
+    assert (prm[0].grad.cpu() - q.grad).abs().max().item() < 1e-4 * q.grad.abs().max().item()
+
+
+def test_loss_curve_vs_oracle_free_running(model):
+    """10 free-running Adam steps, 360x640, 8 cuts: per-step |dloss| <= 1e-3 (north_star tolerance)
+    and final-image pixel RMS stated."""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    h, w, S, steps = 360, 640, 8, 10
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    eng = Engine(p0.to(DEV).contiguous(), h, w, model, S, [(target, -1.0)], sim='mix', transform=transforms.normalize())
+    run = oracle_run(model, h, w, target, p0)
+    seed_all(9)
+    worst = 0.0
+    for i in range(steps):
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got, want = float(eng.step(table)), run.step(table)
+        worst = max(worst, abs(got - want))
+        assert abs(got - want) < 1e-3, (i, got, want)
+    with torch.no_grad():
+        rms = (eng.synthesize(1.1).cpu() - run.image(1.1)[0]).pow(2).mean().sqrt().item()
+    print('loss-curve max |d| %.2e, final pixel RMS %.4f' % (worst, rms))
+    assert rms < 0.05
+
+
+def test_engine_fast_transform_and_dualmodel_smoke(model):
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    h, w, S = 360, 640, 12
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w]).to(DEV).contiguous()
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    eng = Engine(p0, h, w, model, S, [(target, -1.0), (target.flip(1), 0.5)], sim='mix', transform=transforms.transforms_fast)
+    l0 = float(eng.step())
+    for _ in range(8):
+        l = float(eng.step())
+    assert np.isfinite(l) and l < l0            # optimising: the loss goes down
+
+
+def test_full_size_properties(model):
+    """BASELINE size (1280x720, 190 cuts): determinism and adjoint identities, no oracle needed."""
+    H, W, S = 720, 1280, 190
+    seed_all(3)
+    table, _ = __import__('aphantasia_amd.utils', fromlist=['x']).draw_crop_params(S, 224, H, W, 'uniform', 0.4)
+    tb = torch.from_numpy(table).to(DEV)
+    geom = ops.make_geom(H, W, S, 224, 32)
+    img = torch.rand(3, H, W, device=DEV)
+    y = ops.sample_fwd(geom, img, tb, out_mode=_ffi.APH_OUT_NCHW_NORM)
+    g = torch.randn_like(y)
+    gi = ops.sample_bwd(geom, g, tb, out_mode=_ffi.APH_OUT_NCHW_NORM)
+    gi2 = ops.sample_bwd(geom, g, tb, out_mode=_ffi.APH_OUT_NCHW_NORM)
+    assert torch.equal(gi, gi2)                                         # bitwise deterministic gather adjoint
+    # <J x, g> == <x, J^T g> for the (affine) sampler: use differences to cancel the normalisation offset
+    img2 = torch.rand(3, H, W, device=DEV)
+    y2 = ops.sample_fwd(geom, img2, tb, out_mode=_ffi.APH_OUT_NCHW_NORM)
+    lhs = ((y - y2).double() * g.double()).sum().item()
+    rhs = ((img - img2).double() * gi.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs), (lhs, rhs)
+    # synthesis adjoint: <d rgb, g> along a random parameter direction (finite difference, fp32)
+    plan = ops.SynthPlan(3, H, W)
+    seed_all(4)
+    p = (0.01 * torch.randn(3, H, W // 2 + 1, 2)).to(DEV)
+    scale = R.fft_scale(H, W, 1.5).to(DEV)
+    cc = R.colcorr_t(1.8).flatten().tolist()
+    raw, rgb = ops.synth_fft_fwd(plan, p, scale, None, 1.0, cc)
+    gw = torch.randn_like(rgb)
+    grad = ops.synth_fft_bwd(plan, gw, rgb, raw, scale, 1.0, cc)
+    d = torch.randn_like(p)
+    eps = 1e-3 * 0.01
+    _, rp = ops.synth_fft_fwd(plan, p + eps * d, scale, None, 1.0, cc)
+    _, rm = ops.synth_fft_fwd(plan, p - eps * d, scale, None, 1.0, cc)
+    fd = (((rp - rm).double() / (2 * eps)) * gw.double()).sum().item()
+    an = (grad.double() * d.double()).sum().item()
+    assert abs(fd - an) < 2e-2 * abs(an), (fd, an)
