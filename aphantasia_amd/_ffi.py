@@ -8,6 +8,12 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 
+# torch MUST be imported before the library is dlopen'ed: PyTorch-ROCm bundles its own libamdhip64.so
+# (same SONAME as /opt/rocm's).  Loaded first, it satisfies this library's DT_NEEDED entry and the process
+# has ONE HIP runtime; loaded second, the process ends up with two runtimes and the later one to initialise
+# reports "no ROCm-capable device is detected".
+import torch  # noqa: F401  (load order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libaphantasia_hip.so')
 
@@ -44,6 +50,7 @@ _PROTOTYPES = {
     'aph_vit_profile': (c_int, [c_void_p, c_int]),
     'aph_vit_profile_read': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'aph_gemm_f16_ld': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_sim_loss': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
 }

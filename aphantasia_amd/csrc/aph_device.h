@@ -91,6 +91,35 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_f16(half8 a, half8 b, f32x4 c) {
 #endif
 }
 
+// global_load_lds_dwordx4: each lane copies 16 bytes from its own global address straight into LDS at
+// (wave-uniform base) + lane * 16 -- asynchronous, tracked by vmcnt, no VGPR staging.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef APH_EMU
+  memcpy(static_cast<char*>(lds_wave_base) + emu::lane_id() * 16, gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// "at most N vector-memory ops of this wave outstanding, then workgroup barrier" without the full drain that
+// __syncthreads() implies.  The "memory" clobber keeps the compiler's LDS/global accesses on their side.
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+#ifdef APH_EMU
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+
+// all of this wave's LDS reads have returned
+__device__ __forceinline__ void wait_lgkm0() {
+#ifndef APH_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 // v_dot2_f32_f16: c + a.x*b.x + a.y*b.y, fp32 accumulate
 __device__ __forceinline__ float dot2_f16(half2 a, half2 b, float c) {
 #ifdef APH_EMU

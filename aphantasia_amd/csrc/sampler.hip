@@ -12,7 +12,7 @@
 //
 // Adjoint of the crop/resize: deterministic GATHER over crops per image pixel (fixed summation
 // order s = 0..S-1, no atomics) so a given crop table gives bitwise-reproducible gradients.
-// Adjoint of the bilinear warps: fp32 atomics into a per-cut buffer (only the `-tf fast` path).
+// Adjoint of the bilinear warps: gathers through the inverse maps (deterministic as well).
 #include "aph_device.h"
 #include "aph_host.h"
 
@@ -104,88 +104,185 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __r
   }
 }
 
-// Adjoint of crop_resize over all cuts: one thread per source pixel, gather over cuts in fixed order.
-// For the 1-D map dst i -> taps clamp(floor(scale*i) - 1 + k), the cuts' outputs that touch source
-// position q are a contiguous i-range; it is bracketed conservatively and every candidate is
-// re-derived with the forward's own fp32 arithmetic, so weights match the forward bit for bit.
+// Adjoint of crop_resize over all cuts -- deterministic gather, one 16x16 pixel tile per workgroup.
+//   d rgb[y][x] = sum_s sum_{i,j} Wy_s[i][y - oy_s] Wx_s[j][x - ox_s] G_s[i][j]       (fixed order s = 0..S-1)
+// 1. wave 0 culls the S cuts (x wrap-padding aliases) against the tile into an ordered LDS list;
+// 2. per batch of 8 listed cuts, 256 threads build the 1-D tables: for each of the tile's 16 rows and 16
+//    columns the (<= 4, for down-sampling cuts) output indices whose clamped cubic taps land on it, with the
+//    forward's own fp32 weights and the separable gradient-layout offsets;
+// 3. every pixel accumulates its <= 4x4 products per cut.  Work ~ the forward's 16 taps per output pixel.
+// Up-sampling cuts (csize < size, only possible for images smaller than `size`) take the per-pixel generic path.
+struct AdjEntry {
+  int off[4];
+  float w[4];
+};
+
+// separable offset parts of gradient element (i, j) in layout OUT (channel/cut base added by the caller)
 template <int OUT>
-__global__ void crop_resize_adjoint_kernel(const float* __restrict__ gout, float gscale, const int* __restrict__ table,
-                                           float* __restrict__ grgb, Geom g) {
-  __shared__ int tcs[256], tox[256], toy[256];
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+__device__ __forceinline__ int grad_rowpart(int i, int size, int p) {
+  if (OUT == APH_OUT_PATCH_F16) return (i / p) * (size / p) * (3 * p * p) + (i % p) * p;
+  return i * size;
+}
+template <int OUT>
+__device__ __forceinline__ int grad_colpart(int j, int size, int p) {
+  if (OUT == APH_OUT_PATCH_F16) return (j / p) * (3 * p * p) + (j % p);
+  return j;
+}
+
+// weight of output index i on crop-local source position q (sum over clamped taps; forward arithmetic)
+__device__ __forceinline__ float tap_weight(float scale, int i, int cs, int q) {
+  const float sy = scale * (float)i;
+  const int y0 = (int)floorf(sy);
+  float wv[4];
+  cubic_w(sy - (float)y0, wv);
+  float w = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int yy = y0 - 1 + k; yy = yy < 0 ? 0 : (yy > cs - 1 ? cs - 1 : yy);
+    if (yy == q) w += wv[k];
+  }
+  return w;
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* __restrict__ gout, float gscale,
+                                                                  const int* __restrict__ table, float* __restrict__ grgb, Geom g) {
+  constexpr int MAXV = 1024, NB = 8;
+  __shared__ int vlist[MAXV];
+  __shared__ int vcount;
+  __shared__ AdjEntry ent[NB][32];
+  __shared__ int vinfo[NB][2];     // cut index, generic-path flag
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
   const bool live = x < g.W && y < g.H;
+  const int nay = (g.Hp + g.H - 1) / g.H, nax = (g.Wp + g.W - 1) / g.W;     // aliases per axis (1 without overscan)
+  const int nvirt = g.S * nay * nax;
+  const int ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
+  const int cchan = OUT == APH_OUT_PATCH_F16 ? g.patch * g.patch : g.size * g.size;
+  const int ccut = OUT == APH_OUT_PATCH_F16 ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
-  for (int sb = 0; sb < g.S; sb += 256) {
-    const int ns = g.S - sb < 256 ? g.S - sb : 256;
+  for (int vbase = 0; vbase < nvirt; vbase += MAXV) {
+    // ---- 1. ordered compaction by wave 0
     __syncthreads();
-    if ((int)threadIdx.x < ns) {
-      tcs[threadIdx.x] = table[3 * (sb + threadIdx.x)];
-      tox[threadIdx.x] = table[3 * (sb + threadIdx.x) + 1];
-      toy[threadIdx.x] = table[3 * (sb + threadIdx.x) + 2];
+    if (threadIdx.x < 64) {
+      int count = 0;
+      const int vend = nvirt - vbase < MAXV ? nvirt - vbase : MAXV;
+      for (int v0 = 0; v0 < vend; v0 += 64) {
+        const int v = vbase + v0 + threadIdx.x;
+        bool hit = false;
+        if (v0 + (int)threadIdx.x < vend) {
+          const int s = v / (nay * nax), al = v - s * (nay * nax), ay = al / nax, ax = al - ay * nax;
+          const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+          // alias coordinates of the tile's first/last row and column (a wrapping tile is not culled on that axis)
+          const int Ya = wrap(ty0 + g.py0, g.H) + ay * g.H, Yb = wrap(ty0 + 15 + g.py0, g.H) + ay * g.H;
+          const int Xa = wrap(tx0 + g.px0, g.W) + ax * g.W, Xb = wrap(tx0 + 15 + g.px0, g.W) + ax * g.W;
+          const bool yhit = Yb < Ya ? true : (Yb >= oy && Ya < oy + cs);
+          const bool xhit = Xb < Xa ? true : (Xb >= ox && Xa < ox + cs);
+          hit = yhit && xhit;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) vlist[count + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = v;
+        count += __popcll(m);
+      }
+      if (threadIdx.x == 0) vcount = count;
     }
     __syncthreads();
-    for (int q = 0; q < ns; ++q) {
-      const int cs = tcs[q], ox = tox[q], oy = toy[q], s = sb + q;
-      const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
-      const float inv = scale > 0.f ? 1.0f / scale : 0.f;
-      // every padded-frame alias (Y, X) of source pixel (y, x)
-      for (int Y = wrap(y + g.py0, g.H); Y < g.Hp; Y += g.H) {
-        // tile-level cull (block-uniform branch keeps the wave converged on the common skip)
-        const int Yt0 = Y - (y - ty0), Yt1 = Yt0 + 15;
-        if (Yt1 < oy || Yt0 >= oy + cs) continue;
-        for (int X = wrap(x + g.px0, g.W); X < g.Wp; X += g.W) {
-          const int Xt0 = X - (x - tx0), Xt1 = Xt0 + 15;
-          if (Xt1 < ox || Xt0 >= ox + cs) continue;
-          const int yc = Y - oy, xc = X - ox;
-          if (!live || yc < 0 || yc >= cs || xc < 0 || xc >= cs) continue;
-          int ilo, ihi, jlo, jhi;
-          if (scale > 0.f) {
-            ilo = (int)floorf((float)(yc - 2) * inv) - 1; ihi = (int)floorf((float)(yc + 2) * inv) + 1;
-            jlo = (int)floorf((float)(xc - 2) * inv) - 1; jhi = (int)floorf((float)(xc + 2) * inv) + 1;
-          } else { ilo = jlo = 0; ihi = jhi = g.size - 1; }
-          ilo = ilo < 0 ? 0 : ilo; jlo = jlo < 0 ? 0 : jlo;
-          ihi = ihi > g.size - 1 ? g.size - 1 : ihi; jhi = jhi > g.size - 1 ? g.size - 1 : jhi;
-          for (int i = ilo; i <= ihi; ++i) {
-            const float sy = scale * (float)i;
-            const int y0 = (int)floorf(sy);
-            float wv[4];
-            cubic_w(sy - (float)y0, wv);
-            float wy = 0.f;
+    const int nlist = vcount;
+    for (int b0 = 0; b0 < nlist; b0 += NB) {
+      // ---- 2. tables for up to NB cuts: thread -> (cut vb, row/col idx)
+      {
+        const int vb = threadIdx.x >> 5, idx = threadIdx.x & 31;
+        AdjEntry e;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              int yy = y0 - 1 + k; yy = yy < 0 ? 0 : (yy > cs - 1 ? cs - 1 : yy);
-              if (yy == yc) wy += wv[k];
-            }
-            if (wy == 0.f) continue;
-            for (int j = jlo; j <= jhi; ++j) {
-              const float sx = scale * (float)j;
-              const int x0 = (int)floorf(sx);
-              float wu[4];
-              cubic_w(sx - (float)x0, wu);
-              float wx = 0.f;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                int xx = x0 - 1 + k; xx = xx < 0 ? 0 : (xx > cs - 1 ? cs - 1 : xx);
-                if (xx == xc) wx += wu[k];
+        for (int a = 0; a < 4; ++a) { e.off[a] = 0; e.w[a] = 0.f; }
+        if (b0 + vb < nlist) {
+          const int v = vlist[b0 + vb];
+          const int s = v / (nay * nax), al = v - s * (nay * nax), ay = al / nax, ax = al - ay * nax;
+          const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+          const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
+          const bool generic = !(scale >= 1.0f);
+          if (idx == 0) { vinfo[vb][0] = v; vinfo[vb][1] = generic ? 1 : 0; }
+          if (!generic) {
+            const bool isrow = idx < 16;
+            const int q = isrow ? wrap(ty0 + idx + g.py0, g.H) + ay * g.H - oy : wrap(tx0 + (idx - 16) + g.px0, g.W) + ax * g.W - ox;
+            const int lim = isrow ? g.Hp : g.Wp;
+            const int absq = q + (isrow ? oy : ox);
+            if (q >= 0 && q < cs && absq < lim) {
+              const float inv = 1.0f / scale;
+              int lo = (int)floorf((float)(q - 2) * inv) - 1, hi = (int)floorf((float)(q + 2) * inv) + 1;
+              lo = lo < 0 ? 0 : lo; hi = hi > g.size - 1 ? g.size - 1 : hi;
+              int n = 0;
+              for (int i = lo; i <= hi && n < 4; ++i) {
+                const float w = tap_weight(scale, i, cs, q);
+                if (w != 0.f || n > 0) {             // contiguous run starting at the first non-zero
+                  e.w[n] = w;
+                  e.off[n] = isrow ? grad_rowpart<OUT>(i, g.size, g.patch) : grad_colpart<OUT>(i, g.size, g.patch);
+                  ++n;
+                }
               }
-              if (wx == 0.f) continue;
-              const float w = wy * wx;
-              acc0 += w * fetch_grad<OUT>(gout, s, 0, i, j, g.size, g.patch);
-              acc1 += w * fetch_grad<OUT>(gout, s, 1, i, j, g.size, g.patch);
-              acc2 += w * fetch_grad<OUT>(gout, s, 2, i, j, g.size, g.patch);
             }
+          }
+        } else if (idx == 0) { vinfo[vb][0] = -1; vinfo[vb][1] = 0; }
+        ent[vb][idx] = e;
+      }
+      __syncthreads();
+      // ---- 3. accumulate
+      for (int vb = 0; vb < NB; ++vb) {
+        const int v = vinfo[vb][0];
+        if (v < 0) break;
+        const int s = v / (nay * nax);
+        if (vinfo[vb][1]) {
+          // generic per-pixel path (up-sampling cut)
+          const int al = v - s * (nay * nax), ay = al / nax, ax = al - ay * nax;
+          const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+          const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
+          const int Y = wrap(y + g.py0, g.H) + ay * g.H, X = wrap(x + g.px0, g.W) + ax * g.W;
+          const int yc = Y - oy, xc = X - ox;
+          if (live && Y < g.Hp && X < g.Wp && yc >= 0 && yc < cs && xc >= 0 && xc < cs) {
+            const float* gb = gout + (size_t)s * ccut;
+            for (int i = 0; i < g.size; ++i) {
+              const float wy = tap_weight(scale, i, cs, yc);
+              if (wy == 0.f) continue;
+              for (int j = 0; j < g.size; ++j) {
+                const float wx = tap_weight(scale, j, cs, xc);
+                if (wx == 0.f) continue;
+                const int o = grad_rowpart<OUT>(i, g.size, g.patch) + grad_colpart<OUT>(j, g.size, g.patch);
+                acc0 += wy * wx * gb[o];
+                acc1 += wy * wx * gb[o + cchan];
+                acc2 += wy * wx * gb[o + 2 * cchan];
+              }
+            }
+          }
+          continue;
+        }
+        const AdjEntry re = ent[vb][ty], ce = ent[vb][16 + tx];
+        if (re.w[0] == 0.f && re.w[1] == 0.f) continue;     // (a run starts with its first non-zero weight)
+        const float* gb = gout + (size_t)s * ccut;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (re.w[a] == 0.f) continue;
+#pragma unroll
+          for (int bq = 0; bq < 4; ++bq) {
+            if (ce.w[bq] == 0.f) continue;
+            const float w = re.w[a] * ce.w[bq];
+            const int o = re.off[a] + ce.off[bq];
+            acc0 += w * gb[o];
+            acc1 += w * gb[o + cchan];
+            acc2 += w * gb[o + 2 * cchan];
           }
         }
       }
+      __syncthreads();
     }
   }
   if (live) {
     const size_t HW = (size_t)g.H * g.W, o = (size_t)y * g.W + x;
-    grgb[o] = acc0 * gscale;
-    grgb[HW + o] = acc1 * gscale;
-    grgb[2 * HW + o] = acc2 * gscale;
+    const float k0 = OUT == APH_OUT_NCHW_RAW ? gscale : gscale / kClipStd[0];
+    const float k1 = OUT == APH_OUT_NCHW_RAW ? gscale : gscale / kClipStd[1];
+    const float k2 = OUT == APH_OUT_NCHW_RAW ? gscale : gscale / kClipStd[2];
+    grgb[o] = acc0 * k0;
+    grgb[HW + o] = acc1 * k1;
+    grgb[2 * HW + o] = acc2 * k2;
   }
 }
 
@@ -288,31 +385,23 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
   }
 }
 
-template <bool ERASE>
-__device__ __forceinline__ void warp_scatter(float* __restrict__ dst, const Tap& t, int n, const float* __restrict__ a, float gv) {
+// sum of the in-bounds bilinear weights (= the sampled ones-mask of torchvision's fill handling)
+__device__ __forceinline__ float tap_mask(const Tap& t, int n) {
   float m = 0.f;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int yy = t.y0 + dy, xx = t.x0 + dx;
-      if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
-      m += (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
-    }
-  if (m == 0.f) return;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int yy = t.y0 + dy, xx = t.x0 + dx;
-      if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
-      if (ERASE && in_rect(a, yy, xx)) continue;
-      const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
-      atomicAdd(dst + (size_t)yy * n + xx, w * m * gv);
-    }
+  if (t.y0 >= 0 && t.y0 < n) { if (t.x0 >= 0 && t.x0 < n) m += t.wx0 * t.wy0; if (t.x0 + 1 >= 0 && t.x0 + 1 < n) m += t.wx1 * t.wy0; }
+  if (t.y0 + 1 >= 0 && t.y0 + 1 < n) { if (t.x0 >= 0 && t.x0 < n) m += t.wx0 * t.wy1; if (t.x0 + 1 >= 0 && t.x0 + 1 < n) m += t.wx1 * t.wy1; }
+  return m;
+}
+// weight with which output pixel's footprint `t` reads source pixel (py, px); 0 if it does not
+__device__ __forceinline__ float tap_hits(const Tap& t, int py, int px) {
+  const int dy = py - t.y0, dx = px - t.x0;
+  if (dy < 0 || dy > 1 || dx < 0 || dx > 1) return 0.f;
+  return (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
 }
 
-// adjoint of stage 2: gout (layout OUT) -> dC accumulated into dA (cuts without perspective) or dB (with)
+// Adjoint of stage 2 as a GATHER (deterministic, no atomics): thread = source pixel p of the pre-rotation
+// cut; the output pixels whose bilinear footprint contains p lie in the inverse-rotated 2x2 square around p.
+// Each candidate's footprint is re-derived with the forward's own arithmetic.
 template <int OUT>
 __global__ void rotate_emit_adjoint_kernel(const float* __restrict__ gout, const float* __restrict__ aug,
                                            float* __restrict__ dA, float* __restrict__ dB, int n, int patch) {
@@ -320,31 +409,80 @@ __global__ void rotate_emit_adjoint_kernel(const float* __restrict__ gout, const
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= n * n) return;
-  const int i = pix / n, j = pix - i * n;
+  const int py = pix / n, px = pix - py * n;
   float* dst = a[8] != 0.f ? dB : dA;
-  if (a[15] != 0.f) {
-    const Tap t = rot_tap(a[13], a[14], i, j, n);
-    for (int c = 0; c < 3; ++c)
-      warp_scatter<true>(dst + ((size_t)s * 3 + c) * n * n, t, n, a, fetch_grad<OUT>(gout, s, c, i, j, n, patch));
-  } else if (!in_rect(a, i, j)) {
-    for (int c = 0; c < 3; ++c)
-      atomicAdd(dst + ((size_t)s * 3 + c) * n * n + pix, fetch_grad<OUT>(gout, s, c, i, j, n, patch));
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (!in_rect(a, py, px)) {
+    if (a[15] != 0.f) {
+      const float cs = a[13], sn = a[14], c = 0.5f * (float)(n - 1);
+      // forward: (ix, iy) = Rot (q - c) + c with Rot = [[cs, sn], [-sn, cs]]  ->  q = Rot^T (p - c) + c
+      const float ux = (float)px - c, uy = (float)py - c;
+      const float qx = cs * ux - sn * uy + c, qy = sn * ux + cs * uy + c;
+      const float rad = fabsf(cs) + fabsf(sn) + 0.02f;
+      int j0 = (int)ceilf(qx - rad), j1 = (int)floorf(qx + rad), i0 = (int)ceilf(qy - rad), i1 = (int)floorf(qy + rad);
+      j0 = j0 < 0 ? 0 : j0; i0 = i0 < 0 ? 0 : i0; j1 = j1 > n - 1 ? n - 1 : j1; i1 = i1 > n - 1 ? n - 1 : i1;
+      for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+          const Tap t = rot_tap(cs, sn, i, j, n);
+          const float w = tap_hits(t, py, px);
+          if (w == 0.f) continue;
+          const float wm = w * tap_mask(t, n);
+          g0 += wm * fetch_grad<OUT>(gout, s, 0, i, j, n, patch);
+          g1 += wm * fetch_grad<OUT>(gout, s, 1, i, j, n, patch);
+          g2 += wm * fetch_grad<OUT>(gout, s, 2, i, j, n, patch);
+        }
+    } else {
+      g0 = fetch_grad<OUT>(gout, s, 0, py, px, n, patch);
+      g1 = fetch_grad<OUT>(gout, s, 1, py, px, n, patch);
+      g2 = fetch_grad<OUT>(gout, s, 2, py, px, n, patch);
+    }
   }
+  const size_t pl = (size_t)s * 3 * n * n;
+  dst[pl + pix] = g0;
+  dst[pl + (size_t)n * n + pix] = g1;
+  dst[pl + 2 * (size_t)n * n + pix] = g2;
 }
 
-// adjoint of stage 1: dB -> dA for the cuts with perspective
+// Adjoint of stage 1 (perspective) as a gather: dB -> dA (in place of the cut's slot in dA).  Candidates =
+// bounding box of the inverse homography applied to the 2x2 square around p.
 __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* __restrict__ aug, float* __restrict__ dA, int n) {
   const int s = blockIdx.y;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= n * n) return;
-  const int i = pix / n, j = pix - i * n;
-  const Tap t = persp_tap(a, i, j, n);
-  for (int c = 0; c < 3; ++c) {
-    const size_t pl = ((size_t)s * 3 + c) * n * n;
-    warp_scatter<false>(dA + pl, t, n, a, dB[pl + pix]);
+  const int py = pix / n, px = pix - py * n;
+  // forward: (u, v) = H (x, y), x = j + .5, y = i + .5, source index = (u - .5, v - .5);  adj(H) maps back
+  const float m00 = a[4] - a[5] * a[7], m01 = a[2] * a[7] - a[1], m02 = a[1] * a[5] - a[2] * a[4];
+  const float m10 = a[5] * a[6] - a[3], m11 = a[0] - a[2] * a[6], m12 = a[2] * a[3] - a[0] * a[5];
+  const float m20 = a[3] * a[7] - a[4] * a[6], m21 = a[1] * a[6] - a[0] * a[7], m22 = a[0] * a[4] - a[1] * a[3];
+  float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float u = (float)px + 0.5f + ((k & 1) ? 1.01f : -1.01f), v = (float)py + 0.5f + ((k & 2) ? 1.01f : -1.01f);
+    const float d = m20 * u + m21 * v + m22;
+    const float xx = (m00 * u + m01 * v + m02) / d - 0.5f, yy = (m10 * u + m11 * v + m12) / d - 0.5f;
+    xmin = fminf(xmin, xx); xmax = fmaxf(xmax, xx); ymin = fminf(ymin, yy); ymax = fmaxf(ymax, yy);
   }
+  int j0 = (int)ceilf(xmin - 0.05f), j1 = (int)floorf(xmax + 0.05f), i0 = (int)ceilf(ymin - 0.05f), i1 = (int)floorf(ymax + 0.05f);
+  j0 = j0 < 0 ? 0 : j0; i0 = i0 < 0 ? 0 : i0; j1 = j1 > n - 1 ? n - 1 : j1; i1 = i1 > n - 1 ? n - 1 : i1;
+  if (!(xmax - xmin < 64.f && ymax - ymin < 64.f)) { j0 = 0; i0 = 0; j1 = n - 1; i1 = n - 1; }   // degenerate map: exhaustive
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  const size_t pl = (size_t)s * 3 * n * n, nn = (size_t)n * n;
+  for (int i = i0; i <= i1; ++i)
+    for (int j = j0; j <= j1; ++j) {
+      const Tap t = persp_tap(a, i, j, n);
+      const float w = tap_hits(t, py, px);
+      if (w == 0.f) continue;
+      const float wm = w * tap_mask(t, n);
+      const size_t o = pl + (size_t)i * n + j;
+      g0 += wm * dB[o];
+      g1 += wm * dB[o + nn];
+      g2 += wm * dB[o + 2 * nn];
+    }
+  dA[pl + pix] = g0;
+  dA[pl + nn + pix] = g1;
+  dA[pl + 2 * nn + pix] = g2;
 }
 
 // ---------------------------------------------------------------------------------
@@ -427,7 +565,6 @@ int aph_sample_bwd(const aph_sample_geom* gg, const float* gout, float gscale, c
   const size_t per = (size_t)g.S * 3 * n * n;
   float* dA = tmp;
   float* dB = tmp + per;
-  (void)hipMemsetAsync(tmp, 0, sizeof(float) * 2 * per, st);
   const dim3 grid((n * n + 255) / 256, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);

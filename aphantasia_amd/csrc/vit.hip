@@ -12,6 +12,7 @@
 #include "aph_host.h"
 #include "vit_gemm.h"
 #include "vit_ops.h"
+#include "vit_attn.h"
 
 using namespace aph;
 
@@ -245,7 +246,10 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
     launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
     vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
-    APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
+    if (T <= AT_T)
+      APH_LAUNCH(attn_fwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
+    else
+      APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
     vgemm(v, l.att, D, l.w_o, D, M, D, D, EpiResidual{l.x_mid, l.x_in, D, l.b_o}, st);
     launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, M, T, nullptr, nullptr, nullptr, st);
     vgemm(v, v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
@@ -273,8 +277,12 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, M, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, M, T, st);
     vgemm(v, v->dx16, D, l.w_oT, D, M, D, D, EpiF16{v->datt, D, nullptr}, st);
-    APH_LAUNCH(attn_bwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)4 * T * 128 + 8 * T, st, (const half_t*)l.qkv,
-               (const half_t*)l.att, (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+    if (T <= AT_T)
+      APH_LAUNCH(attn_bwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
+                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+    else
+      APH_LAUNCH(attn_bwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)4 * T * 128 + 8 * T, st, (const half_t*)l.qkv,
+                 (const half_t*)l.att, (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
   }
@@ -316,6 +324,16 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
   launch_gemm((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
   return aph_check_launch("aph_gemm_f16");
+  APH_CATCH
+}
+
+// same with explicit leading dimensions (row pitches in elements) -- layout experiments
+int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, void* stream_) {
+  APH_TRY
+  if (!d_A || !d_Bt || !d_C || M < 1 || N % GEMM_BN || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7))
+    return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
+  launch_gemm((const half_t*)d_A, lda, (const half_t*)d_Bt, ldb, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
+  return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH
 }
 

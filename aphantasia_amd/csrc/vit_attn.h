@@ -1,0 +1,239 @@
+// Matrix-core attention for short sequences (T <= 64 tokens: CLIP ViT-B/32 has T = 50), head dim 64.
+// One workgroup (4 waves) per (image, head); wave w owns the 16-row tile w.  fp16 operands, fp32
+// accumulation and softmax statistics.
+//
+// Layout trick (cdna_hip_programming.md T12, "make the reduction axis lane-local"): scores are formed
+// TRANSPOSED, S^T = K Q^T, so that in the MFMA C/D layout every lane owns ONE query (column l & 15)
+// and 4 consecutive keys per 16-key tile; the row softmax is then lane-local (+2 shuffles), and the
+// exponentiated tile pairs are ALREADY a valid B-operand fragment for the next product if the other
+// operand is stored with its reduction index permuted the same way:
+//     slot(n) = (n >> 5) * 32 + ((n >> 2) & 3) * 8 + ((n >> 4) & 1) * 4 + (n & 3)
+// so V / K / Q / dO are staged into LDS once as transposed, slot-permuted images [d][slot] and no
+// probability matrix ever moves between lanes or through LDS.
+#pragma once
+#include "aph_device.h"
+#include "vit_gemm.h"
+
+namespace aph {
+
+constexpr int AT_T = 64;                       // padded sequence length
+__device__ __forceinline__ int slot_of(int n) { return ((n >> 5) << 5) + (((n >> 2) & 3) << 3) + (((n >> 4) & 1) << 2) + (n & 3); }
+
+// [64 rows][64 halfs] tile, 16-byte chunks XOR-swizzled exactly like the GEMM tiles (conflict-free b128 reads)
+__device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+__device__ __forceinline__ void at_zero(half_t* lds, int halfs) {
+  const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = threadIdx.x; q < halfs / 8; q += blockDim.x) *reinterpret_cast<half8*>(lds + q * 8) = z;
+}
+
+// stage T rows x 64 halfs from global (row stride ld) into a swizzled row-major tile and/or its
+// transposed slot-permuted image
+__device__ __forceinline__ void at_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed) {
+  for (int q = threadIdx.x; q < T * 8; q += blockDim.x) {
+    const int r = q >> 3, c = q & 7;
+    const half8 v = *reinterpret_cast<const half8*>(src + (size_t)r * ld + c * 8);
+    if (rowmajor) *reinterpret_cast<half8*>(rowmajor + at_off(r, c)) = v;
+    if (transposed) {
+      const int s = slot_of(r), sc = s >> 3, sw = s & 7;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) transposed[at_off(c * 8 + e, sc) + sw] = v[e];
+    }
+  }
+}
+
+__device__ __forceinline__ half8 at_frag(const half_t* tile, int row, int chunk) {
+  return *reinterpret_cast<const half8*>(tile + at_off(row, chunk));
+}
+
+__device__ __forceinline__ half8 pack8(const f32x4& a, const f32x4& b) {
+  half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  return h;
+}
+
+// qkv [M,3D] f16 -> att [M,D] f16, lse [S*heads*T] f32 (log-sum-exp of the scaled scores)
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att,
+                                                           float* __restrict__ lse, int T, int heads) {
+  __shared__ __attribute__((aligned(16))) half_t lds[3 * 64 * 64];
+  half_t* Qs = lds;
+  half_t* Ks = lds + 64 * 64;
+  half_t* Vt = lds + 2 * 64 * 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  at_zero(lds, 3 * 64 * 64);
+  __syncthreads();
+  at_stage(base, ld, T, Qs, nullptr);
+  at_stage(base + D, ld, T, Ks, nullptr);
+  at_stage(base + 2 * D, ld, T, nullptr, Vt);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, it = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  if (it * 16 >= T) return;
+  f32x4 st[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd) {
+    const half8 qf = at_frag(Qs, it * 16 + c16, kd * 4 + g);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) st[jt] = mfma_16x16x32_f16(at_frag(Ks, jt * 16 + c16, kd * 4 + g), qf, st[jt]);
+  }
+  // lane: query i = it*16 + c16, keys j = jt*16 + g*4 + r
+  float mx = -1e30f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = jt * 16 + g * 4 + r < T;
+      st[jt][r] = ok ? st[jt][r] * 0.125f : -1e30f;
+      mx = fmaxf(mx, st[jt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] - mx) : 0.f;
+      st[jt][r] = p;
+      l += p;
+    }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const half8 p0 = pack8(st[0], st[1]), p1 = pack8(st[2], st[3]);
+  const float inv = 1.0f / l;
+  const int i = it * 16 + c16;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, g), p0, o);
+    o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, 4 + g), p1, o);
+    if (i < T) store_h4(att + ((size_t)s * T + i) * D + h * 64 + dt * 16 + g * 4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  }
+  if (g == 0 && i < T) lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
+}
+
+// backward: (qkv, att, lse, datt) -> dqkv [M,3D] f16
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
+                                                           const half_t* __restrict__ datt, const float* __restrict__ lse,
+                                                           half_t* __restrict__ dqkv, int T, int heads) {
+  __shared__ __attribute__((aligned(16))) half_t lds[7 * 64 * 64 + 256];
+  half_t* Qs = lds;
+  half_t* Ks = lds + 1 * 4096;
+  half_t* Vs = lds + 2 * 4096;
+  half_t* Os = lds + 3 * 4096;   // dO
+  half_t* Qt = lds + 4 * 4096;
+  half_t* Kt = lds + 5 * 4096;
+  half_t* Ot = lds + 6 * 4096;   // dO transposed
+  float* Ls = reinterpret_cast<float*>(lds + 7 * 4096);
+  float* Ds = Ls + 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  const half_t* dob = datt + (size_t)s * T * D + h * 64;
+  const half_t* ob = att + (size_t)s * T * D + h * 64;
+  at_zero(lds, 7 * 4096);
+  __syncthreads();
+  at_stage(base, ld, T, Qs, Qt);
+  at_stage(base + D, ld, T, Ks, Kt);
+  at_stage(base + 2 * D, ld, T, Vs, nullptr);
+  at_stage(dob, D, T, Os, Ot);
+  {
+    // D_i = dO_i . O_i : 4 threads per row
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float a = 0.f;
+    if (r < T) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const half8 x = *reinterpret_cast<const half8*>(ob + (size_t)r * D + part * 16 + c * 8);
+        const half8 y = *reinterpret_cast<const half8*>(dob + (size_t)r * D + part * 16 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)x[e] * (float)y[e];
+      }
+    }
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (part == 0) {
+      Ds[r] = a;
+      Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+  if (w * 16 < T) {
+    // ---- phase A: wave = query tile.  S^T = K Q^T, dP^T = V dO^T (lane: query i, keys jt*16 + g*4 + r)
+    const int it = w, i = it * 16 + c16;
+    f32x4 st[4], dp[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { st[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      const half8 qf = at_frag(Qs, i, kd * 4 + g), of = at_frag(Os, i, kd * 4 + g);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        st[jt] = mfma_16x16x32_f16(at_frag(Ks, jt * 16 + c16, kd * 4 + g), qf, st[jt]);
+        dp[jt] = mfma_16x16x32_f16(at_frag(Vs, jt * 16 + c16, kd * 4 + g), of, dp[jt]);
+      }
+    }
+    const float Li = Ls[i], Di = Ds[i];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] * 0.125f - Li) : 0.f;
+        st[jt][r] = p * (dp[jt][r] - Di) * 0.125f;      // dS^T
+      }
+    const half8 d0 = pack8(st[0], st[1]), d1 = pack8(st[2], st[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, g), d0, o);
+      o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, 4 + g), d1, o);
+      if (i < T) store_h4(dbase + (size_t)i * ld + dt * 16 + g * 4, o[0], o[1], o[2], o[3]);
+    }
+    // ---- phase B: wave = key tile.  S = Q K^T, dP = dO V^T (lane: key j, queries it*16 + g*4 + r)
+    const int jt = w, j = jt * 16 + c16;
+    f32x4 sq[4], dq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { sq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      const half8 kf = at_frag(Ks, j, kd * 4 + g), vf = at_frag(Vs, j, kd * 4 + g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sq[t] = mfma_16x16x32_f16(at_frag(Qs, t * 16 + c16, kd * 4 + g), kf, sq[t]);
+        dq[t] = mfma_16x16x32_f16(at_frag(Os, t * 16 + c16, kd * 4 + g), vf, dq[t]);
+      }
+    }
+    f32x4 pp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + t * 16 + g * 4);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = t * 16 + g * 4 + r < T ? __expf(sq[t][r] * 0.125f - L4[r]) : 0.f;
+        pp[t][r] = p;
+        sq[t][r] = p * (dq[t][r] - D4[r]) * 0.125f;     // dS
+      }
+    }
+    const half8 p0 = pack8(pp[0], pp[1]), p1 = pack8(pp[2], pp[3]);
+    const half8 s0 = pack8(sq[0], sq[1]), s1 = pack8(sq[2], sq[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
+      ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, g), p0, ov);
+      ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, 4 + g), p1, ov);
+      ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, g), s0, ok);
+      ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, 4 + g), s1, ok);
+      if (j < T) {
+        store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[0], ok[1], ok[2], ok[3]);
+        store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[0], ov[1], ov[2], ov[3]);
+      }
+    }
+  }
+}
+
+}  // namespace aph

@@ -32,7 +32,19 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const half_t* __restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM;
+  // XCD-aware tile order (T1): workgroup b runs on XCD b % 8 (observed dispatch, speed only).  Give every
+  // XCD one contiguous run of tiles, n-tiles fastest, so the column tiles that re-read the same 128-row A
+  // panel share one L2 instead of pulling it through the fabric into eight.  Bijective for any grid size.
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntn = N / GEMM_BN;
+    const int tm = tile / ntn;
+    n0 = (tile - tm * ntn) * GEMM_BN;
+    m0 = tm * GEMM_BM;
+  }
 
   // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
   const half_t* ga[4];
@@ -112,6 +124,125 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const half_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-M variant: 256x128x64 block tile, 8 waves (4x2, 64x64 each).
+//  * operands stream straight into LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass)
+//    through a 3-stage ring with COUNTED vmcnt waits and a raw s_barrier (one barrier per k-tile);
+//  * the LDS -> register fragment loads are software-pipelined one k-step (32) ahead of the MFMAs, ACROSS the
+//    tile barrier: while the matrix cores work on k-step s, the ds_reads of k-step s+1 are in flight, so the
+//    LDS latency never sits between a barrier and the first MFMA of a tile.
+// Arithmetic intensity of the tile is 85 flop per L2 byte (128x128: 64).  The LDS image written by the DMA is
+// lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address and undone by the fragment reads
+// (cdna_hip_programming.md rule 21).
+// ---------------------------------------------------------------------------------------------
+constexpr int GB_BM = 256, GB_BN = 128, GB_BK = 64;
+constexpr int GB_STAGE = (GB_BM + GB_BN) * GB_BK;          // halfs per stage (48 KiB)
+constexpr int GB_NSTAGE = 3;
+constexpr int GB_SMEM = GB_NSTAGE * GB_STAGE * 2;          // bytes (144 KiB: one workgroup per CU)
+
+struct GbFrags {
+  half8 a[4], b[4];
+};
+
+__device__ __forceinline__ void gb_load_frags(GbFrags& f, const half_t* As, const half_t* Bs, int arow, int brow, int chunk) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f.a[t] = *reinterpret_cast<const half8*>(As + lds_off(arow + t * 16, chunk));
+    f.b[t] = *reinterpret_cast<const half8*>(Bs + lds_off(brow + t * 16, chunk));
+  }
+}
+__device__ __forceinline__ void gb_mma(f32x4 (&acc)[4][4], const GbFrags& f) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f.b[nt], f.a[mt], acc[mt][nt]);
+}
+
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_f16_big_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
+                                                           int ldb, int M, int N, int K, Epi epi) {
+  APH_DYN_SMEM(smem);
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntn = N / GB_BN;
+    const int tm = tile / ntn;
+    n0 = (tile - tm * ntn) * GB_BN;
+    m0 = tm * GB_BM;
+  }
+  // DMA assignment: one instruction = 64 lanes x 16 B = 8 tile rows.  A: 32 row groups (4 per wave), B: 16 (2 per wave).
+  const half_t* ga[4];
+  const half_t* gb[2];
+  const int lrow = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = (wave * 4 + k) * 8 + lrow;
+    int am = m0 + row; am = am < M ? am : M - 1;
+    ga[k] = A + (size_t)am * lda + ((pc ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = (wave * 2 + k) * 8 + lrow;
+    gb[k] = Bt + (size_t)(n0 + row) * ldb + ((pc ^ ((row >> 1) & 7)) << 3);
+  }
+  auto issue = [&](int kt, int stage) {
+    half_t* As = lds + stage * GB_STAGE;
+    half_t* Bs = As + GB_BM * GB_BK;
+    const int ko = kt * GB_BK;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) glds16(ga[k] + ko, As + (wave * 4 + k) * 8 * GB_BK);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) glds16(gb[k] + ko, Bs + (wave * 2 + k) * 8 * GB_BK);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / GB_BK;
+  const int arow = wm * 64 + (lane & 15), brow = wn * 64 + (lane & 15), fchunk = lane >> 4;
+  // Ring protocol per tile kt (stage kt % 3):   own DMAs of tile kt retired (counted vmcnt: the 6 of tile kt+1
+  // stay in flight) -> s_barrier (everyone's retired; everyone's fragment reads of tile kt-1 are complete, so its
+  // stage may be refilled) -> issue tile kt+2 -> read fragments of tile kt.
+  GbFrags f0, f1;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) wait_vm_barrier<6>(); else wait_vm_barrier<0>();
+  if (nk > 2) issue(2, 2);
+  gb_load_frags(f0, lds, lds + GB_BM * GB_BK, arow, brow, fchunk);
+  int st_cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* As = lds + st_cur * GB_STAGE;
+    const half_t* Bs = As + GB_BM * GB_BK;
+    gb_load_frags(f1, As, Bs, arow, brow, 4 + fchunk);     // k-step 1 of tile kt: in flight during the MFMAs below
+    gb_mma(acc, f0);                                        // k-step 0 of tile kt
+    st_cur = st_cur == GB_NSTAGE - 1 ? 0 : st_cur + 1;
+    if (kt + 1 < nk) {
+      wait_lgkm0();                                         // f1 has left LDS: stage st(kt) is dead for this wave
+      if (kt + 2 < nk) wait_vm_barrier<6>(); else wait_vm_barrier<0>();
+      if (kt + 3 < nk) issue(kt + 3, st_cur == 0 ? GB_NSTAGE - 1 : st_cur - 1);   // refill the stage just released
+      const half_t* An = lds + st_cur * GB_STAGE;
+      gb_load_frags(f0, An, An + GB_BM * GB_BK, arow, brow, fchunk);   // k-step 0 of tile kt+1: overlaps the MFMAs below
+    }
+    gb_mma(acc, f1);                                        // k-step 1 of tile kt
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
+    if (m < M) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) epi(m, n0 + wn * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
+    }
+  }
+}
+
 // ---- epilogues (called with 4 consecutive columns n..n+3 of row m) ---------------------------
 __device__ __forceinline__ void store_h4(half_t* p, float a, float b, float c, float d) {
   half4 h = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
@@ -180,7 +311,13 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
 
 template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  APH_LAUNCH(gemm_f16_kernel<Epi>, dim3(N / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, epi);
+  if (M >= 2048) {
+    static bool once = (APH_ALLOW_SMEM(gemm_f16_big_kernel<Epi>, GB_SMEM), true);
+    (void)once;
+    APH_LAUNCH(gemm_f16_big_kernel<Epi>, dim3((N / GB_BN) * ((M + GB_BM - 1) / GB_BM)), dim3(512), GB_SMEM, st, A, lda, Bt, ldb, M, N, K, epi);
+    return;
+  }
+  APH_LAUNCH(gemm_f16_kernel<Epi>, dim3((N / GEMM_BN) * ((M + GEMM_BM - 1) / GEMM_BM)), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, epi);
 }
 
 }  // namespace aph

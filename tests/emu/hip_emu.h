@@ -208,6 +208,17 @@ template <typename T> inline T __shfl_xor(T v, int m) { return __shfl(v, emu::la
 template <typename T> inline T __shfl_down(T v, int d) { int l = emu::lane_id(); return __shfl(v, l + d < 64 ? l + d : l); }
 template <typename T> inline T __shfl_up(T v, int d) { int l = emu::lane_id(); return __shfl(v, l - d >= 0 ? l - d : l); }
 
+inline unsigned long long __ballot(int pred) {
+  unsigned char v = pred ? 1 : 0;
+  memcpy(emu::wave_slot(emu::lane_id()), &v, 1);
+  emu::wave_barrier();
+  unsigned long long m = 0;
+  const int base = emu::wave_id() * 64, nt = emu::B()->nthreads;
+  for (int l = 0; l < 64 && base + l < nt; ++l) if (*emu::wave_slot(l)) m |= 1ull << l;
+  emu::wave_barrier();
+  return m;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }

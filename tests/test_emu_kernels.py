@@ -59,7 +59,14 @@ def test_adam(emu):
 
 def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(100, 128, 64), (130, 256, 192)])
+    K.check_gemm(emu, 'cpu', [(2100, 128, 192)])          # large-M variant (256x128 tile, LDS-DMA staging)
 
 
 def test_vit(emu):
     K.check_vit(emu, 'cpu')
+
+
+def test_vit_50_tokens(emu):
+    # T = 50 like ViT-B/32: four 16-row attention tiles with a ragged last one
+    cfg = dict(input_resolution=112, patch_size=16, width=256, layers=1, heads=4, output_dim=128)
+    K.check_vit(emu, 'cpu', cfg, S=2)

@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from aphantasia_amd import _ffi, ops
 from aphantasia_amd.weights import synthetic_visual_weights, visual_config
 
