@@ -37,6 +37,8 @@ _PROTOTYPES = {
     'aph_synth_spatial_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_synth_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
     'aph_synth_set_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'aph_idwt_level_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    'aph_idwt_level_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'aph_sample_fwd': (c_int, [POINTER(SampleGeom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_sample_bwd': (c_int, [POINTER(SampleGeom), c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_patchify_f16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -51,7 +53,7 @@ _PROTOTYPES = {
     'aph_vit_profile_read': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_gemm_f16_ld': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'aph_sim_loss': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'aph_sim_loss': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
 }
 

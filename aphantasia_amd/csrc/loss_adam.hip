@@ -10,13 +10,22 @@ namespace aph {
 
 enum { SIM_COS = 0, SIM_MIX = 1, SIM_ANG = 2, SIM_DOT = 3 };
 
+// Target buffer = n_broadcast rows [D] (text prompts: one embedding against every cut) followed by
+// (T - n_broadcast) blocks [s_total, D] of per-cut targets (the reference-image term pairs cut s with
+// slice s of the input image, clip_fft.py:216,267); s_offset = first global cut of this rank's shard.
+struct TargetLayout { int n_broadcast, s_total, s_offset; };
+__device__ __forceinline__ const float* tgt_row(const float* tgt, int t, int s, int D, TargetLayout L) {
+  if (t < L.n_broadcast) return tgt + (size_t)t * D;
+  return tgt + ((size_t)L.n_broadcast + (size_t)(t - L.n_broadcast) * L.s_total + L.s_offset + s) * D;
+}
+
 // One workgroup per sample: per-target value terms and d loss / d enc[s].
 //   enc [S,D] f32, tgt [T,D] f32, coef [T] f32 (sign*weight), denom = number of samples in the GLOBAL
 //   mean (S, or the all-rank total when samples are sharded across ranks).
 //   partial[s] = sum_t coef_t * (per-sample term) ; loss = sum_s partial[s] / denom   (not for SIM_DOT)
 __global__ void sim_loss_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, const float* __restrict__ coef,
                                 int T, int D, int type, float denom, float gscale, float* __restrict__ partial,
-                                float* __restrict__ genc) {
+                                float* __restrict__ genc, TargetLayout lay) {
   __shared__ float red[16];
   const int s = blockIdx.x;
   const float* e = enc + (size_t)s * D;
@@ -27,7 +36,7 @@ __global__ void sim_loss_kernel(const float* __restrict__ enc, const float* __re
   float total = 0.f;
   for (int d = threadIdx.x; d < D; d += blockDim.x) genc[(size_t)s * D + d] = 0.f;
   for (int t = 0; t < T; ++t) {
-    const float* v = tgt + (size_t)t * D;
+    const float* v = tgt_row(tgt, t, s, D, lay);
     float dot = 0.f, vv = 0.f;
     for (int d = threadIdx.x; d < D; d += blockDim.x) { dot += v[d] * e[d]; vv += v[d] * v[d]; }
     dot = block_sum(dot, red);
@@ -70,7 +79,7 @@ __global__ void sim_loss_kernel(const float* __restrict__ enc, const float* __re
 //   dot = sum_{s,d} v[d] e[s,d]; mag = sqrt(sum e^2); loss_t = dot * dot / (1e-6 + mag)
 // Pass 1: per-sample partial sums (dotsum per target, sumsq);  pass 2: gradient.
 __global__ void sim_dot_partial_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, int T, int D,
-                                       float* __restrict__ part /*[S, T+1]*/) {
+                                       float* __restrict__ part /*[S, T+1]*/, TargetLayout lay) {
   __shared__ float red[16];
   const int s = blockIdx.x;
   const float* e = enc + (size_t)s * D;
@@ -80,14 +89,15 @@ __global__ void sim_dot_partial_kernel(const float* __restrict__ enc, const floa
   if (threadIdx.x == 0) part[(size_t)s * (T + 1) + T] = ee;
   for (int t = 0; t < T; ++t) {
     float dot = 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) dot += tgt[(size_t)t * D + d] * e[d];
+    const float* v = tgt_row(tgt, t, s, D, lay);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dot += v[d] * e[d];
     dot = block_sum(dot, red);
     if (threadIdx.x == 0) part[(size_t)s * (T + 1) + t] = dot;
   }
 }
 __global__ void sim_dot_grad_kernel(const float* __restrict__ enc, const float* __restrict__ tgt, const float* __restrict__ coef,
                                     const float* __restrict__ part, int S, int T, int D, float gscale,
-                                    float* __restrict__ loss_out, float* __restrict__ genc) {
+                                    float* __restrict__ loss_out, float* __restrict__ genc, TargetLayout lay) {
   __shared__ float sums[64];
   // every block recomputes the global sums deterministically (S, T are small)
   if ((int)threadIdx.x <= T && threadIdx.x < 64) {
@@ -105,7 +115,7 @@ __global__ void sim_dot_grad_kernel(const float* __restrict__ enc, const float* 
       const float dot = sums[t];
       // f = dot^2 / (1e-6 + mag): df/de = 2 dot v / (eps+mag) - dot^2 / (eps+mag)^2 * e / mag
       const float q = 1e-6f + mag;
-      g += coef[t] * (2.f * dot * tgt[(size_t)t * D + d] / q - dot * dot / (q * q) * (mag > 0.f ? enc[(size_t)s * D + d] / mag : 0.f));
+      g += coef[t] * (2.f * dot * tgt_row(tgt, t, s, D, lay)[d] / q - dot * dot / (q * q) * (mag > 0.f ? enc[(size_t)s * D + d] / mag : 0.f));
     }
     genc[(size_t)s * D + d] = g * gscale;
   }
@@ -160,15 +170,19 @@ extern "C" {
 // loss (device scalar) = sum_t coef_t * sim_t ;  d_genc = gscale * d loss / d enc.
 // denom: sample count of the global mean (== S unless samples are sharded over ranks).
 int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const float* d_coef, const float* h_coef, int T,
-                 int type, float denom, float gscale, float* d_ws, float* d_loss, float* d_genc, void* stream_) {
+                 int n_broadcast, int s_total, int s_offset, int type, float denom, float gscale, float* d_ws, float* d_loss,
+                 float* d_genc, void* stream_) {
   APH_TRY
   if (!d_enc || !d_targets || !d_coef || !d_ws || !d_loss || !d_genc || S < 1 || D < 1 || T < 1 || T > 62)
     return aph_fail(APH_ERR_ARG, "aph_sim_loss: bad argument (S=%d D=%d T=%d)", S, D, T);
   if (type < 0 || type > 3) return aph_fail(APH_ERR_ARG, "aph_sim_loss: unknown similarity type %d", type);
+  if (n_broadcast < 0 || n_broadcast > T || (n_broadcast < T && (s_offset < 0 || s_offset + S > s_total)))
+    return aph_fail(APH_ERR_ARG, "aph_sim_loss: bad target layout (n_broadcast=%d T=%d s_total=%d s_offset=%d S=%d)", n_broadcast, T, s_total, s_offset, S);
+  const TargetLayout lay{n_broadcast, s_total, s_offset};
   hipStream_t st = (hipStream_t)stream_;
   if (type == SIM_DOT) {
-    APH_LAUNCH(sim_dot_partial_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, T, D, d_ws);
-    APH_LAUNCH(sim_dot_grad_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, (const float*)d_ws, S, T, D, gscale, d_loss, d_genc);
+    APH_LAUNCH(sim_dot_partial_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, T, D, d_ws, lay);
+    APH_LAUNCH(sim_dot_grad_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, (const float*)d_ws, S, T, D, gscale, d_loss, d_genc, lay);
     return aph_check_launch("aph_sim_loss");
   }
   float base = 0.f;
@@ -176,7 +190,7 @@ int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const
     if (!h_coef) return aph_fail(APH_ERR_ARG, "aph_sim_loss: 'ang' needs host coefficients");
     for (int t = 0; t < T; ++t) base += h_coef[t];
   }
-  APH_LAUNCH(sim_loss_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, T, D, type, denom, gscale, d_ws, d_genc);
+  APH_LAUNCH(sim_loss_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, T, D, type, denom, gscale, d_ws, d_genc, lay);
   APH_LAUNCH(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)d_ws, S, denom, base, d_loss);
   return aph_check_launch("aph_sim_loss");
   APH_CATCH

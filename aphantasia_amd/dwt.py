@@ -1,0 +1,95 @@
+"""Wavelet (DWT) image parameteriser: host side of `dwt_image` (aphantasia/image.py:33-80).
+
+All coefficient tensors live in ONE flat fp32 buffer (Yl, then every detail level, finest first -- the order
+of the reference's `Ys` list); the per-tensor views handed to Python share that storage, so the fused engine
+can run Adam and the multi-GPU all-reduce on the flat buffer while `torch.save(Ys)` / torch.optim keep working.
+The inverse transform is one HIP launch per level (csrc/dwt.hip), coarsest first.
+"""
+import math
+
+import torch
+
+from . import _ffi, ops
+from .wavelet_filters import REC_LO
+
+
+def max_level(h, w):
+    """pywt.WaveletPacket2D(zeros(h,w), 'db1', 'symmetric').maxlevel (image.py:35-36) = floor(log2(min(h,w)))"""
+    return int(math.floor(math.log2(min(h, w))))
+
+
+def coeff_shapes(h, w, wave):
+    """DWTForward(J, wave, 'symmetric') coefficient sizes, finest first: n -> (n + L - 1) // 2"""
+    if wave not in REC_LO:
+        raise ValueError('unknown wavelet %r (available: %s)' % (wave, ', '.join(sorted(REC_LO))))
+    L = len(REC_LO[wave])
+    J = max_level(h, w)
+    sizes = []
+    for _ in range(J):
+        h, w = (h + L - 1) // 2, (w + L - 1) // 2
+        sizes.append((h, w))
+    return J, sizes
+
+
+def dwt_scale_from_sizes(sizes, sharp):
+    """image.py:73-80"""
+    h0, w0 = sizes[0]
+    return [((h0 * w0) / (h * w)) ** (1. - sharp) for (h, w) in sizes]
+
+
+class DWTSynth:
+    """Coefficient storage + the level-by-level inverse transform and its adjoint."""
+
+    def __init__(self, h, w, wave, sharp, device, lib=None, C=3):
+        self.lib = lib if lib is not None else _ffi.lib()
+        self.C, self.wave, self.sharp = C, wave, sharp
+        self.J, self.sizes = coeff_shapes(h, w, wave)
+        self.L = len(REC_LO[wave])
+        g0 = torch.tensor(REC_LO[wave], dtype=torch.float64)
+        g1 = torch.tensor([(-1) ** k * REC_LO[wave][self.L - 1 - k] for k in range(self.L)], dtype=torch.float64)
+        self.g0, self.g1 = g0.float().to(device), g1.float().to(device)
+        self.scale = dwt_scale_from_sizes(self.sizes, sharp)
+        # flat layout: [Yl | Yh_0 (finest) | Yh_1 | ...]
+        hJ, wJ = self.sizes[-1]
+        self.shapes = [(1, C, hJ, wJ)] + [(1, C, 3, hh, ww) for (hh, ww) in self.sizes]
+        self.offsets, n = [], 0
+        for s in self.shapes:
+            self.offsets.append(n)
+            n += math.prod(s)
+        self.numel = n
+        # running low band after each level, coarsest -> finest; out size of level j = 2 n_j - L + 2
+        self.out_sizes = [(2 * hh - self.L + 2, 2 * ww - self.L + 2) for (hh, ww) in self.sizes]
+        self.H, self.W = self.out_sizes[0]
+        self.bufs = [torch.empty(C, *s, dtype=torch.float32, device=device) for s in self.out_sizes]
+        self.gbufs = [torch.empty(C, *s, dtype=torch.float32, device=device) for s in self.out_sizes]
+
+    def views(self, flat):
+        return [flat[o:o + math.prod(s)].view(s) for o, s in zip(self.offsets, self.shapes)]
+
+    def forward(self, flat):
+        """flat coefficient buffer -> raw image [C, H, W] (the tensor is owned by this object)"""
+        ys = self.views(flat)
+        st = ops._stream(flat)
+        ll, llh, llw = ys[0], self.sizes[-1][0], self.sizes[-1][1]
+        for j in range(self.J - 1, -1, -1):
+            hh, ww = self.sizes[j]
+            self.lib.call('aph_idwt_level_fwd', ops.ptr(ll), llh, llw, ops.ptr(ys[1 + j]), hh, ww, self.C, ops.ptr(self.g0),
+                          ops.ptr(self.g1), self.L, float(self.scale[j]), ops.ptr(self.bufs[j]), st)
+            ll, (llh, llw) = self.bufs[j], self.out_sizes[j]
+        return self.bufs[0]
+
+    def backward(self, d_raw, grad_flat):
+        """d_raw [C,H,W] -> gradient w.r.t. every coefficient, written into grad_flat (same layout as the params)"""
+        gs = self.views(grad_flat)
+        st = ops._stream(grad_flat)
+        g = d_raw
+        for j in range(self.J):
+            hh, ww = self.sizes[j]
+            if j + 1 < self.J:
+                dst, (llh, llw) = self.gbufs[j + 1], self.out_sizes[j + 1]
+            else:
+                dst, (llh, llw) = gs[0], self.sizes[-1]
+            self.lib.call('aph_idwt_level_bwd', ops.ptr(g), hh, ww, self.C, ops.ptr(self.g0), ops.ptr(self.g1), self.L,
+                          float(self.scale[j]), ops.ptr(dst), llh, llw, ops.ptr(gs[1 + j]), st)
+            g = dst
+        return grad_flat

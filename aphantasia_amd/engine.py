@@ -34,8 +34,9 @@ def shard_range(S, rank, world):
 class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
-                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None):
-        """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel');
+                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None):
+        """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
+        coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
         coef = sign*weight as at clip_fft.py:257-267."""
         self.params = params
@@ -55,6 +56,10 @@ class Engine:
         self.cc = colcorr_t(colors).flatten().tolist()
         self.decorrelate = decorrelate
         self.lib = lib if lib is not None else _ffi.lib()
+        self.dwt = dwt
+        if param_kind == 'dwt':
+            h, w = dwt.H, dwt.W                  # the synthesised image may be one row/col larger than requested
+            self.h, self.w = h, w
         self.plan = ops.SynthPlan(3, h, w, lib=self.lib)
         self.scale = fft_scale(h, w, decay).to(self.dev).contiguous() if param_kind == 'fft' else None
         self.lr = lr
@@ -65,10 +70,11 @@ class Engine:
         self.amsgrad = name == 'adamw_custom'
         n = params.numel()
         f32 = dict(dtype=torch.float32, device=self.dev)
-        self.m = torch.zeros(n, **f32) if self.beta1 else None
-        self.v = torch.zeros(n, **f32)
-        self.vmax = torch.zeros(n, **f32) if self.amsgrad else None
-        self.step_count = 0
+        if state is None:        # optimiser state; `state=other.state()` shares it (the --dualmod engines, clip_fft.py:243-252)
+            state = dict(m=torch.zeros(n, **f32) if self.beta1 else None, v=torch.zeros(n, **f32),
+                         vmax=torch.zeros(n, **f32) if self.amsgrad else None, step=[0])
+        self._state = state
+        self.m, self.v, self.vmax = state['m'], state['v'], state['vmax']
         self.set_targets(targets)
         # static buffers
         self.visual.ensure_batch(max(self.S_loc, 1))
@@ -93,9 +99,24 @@ class Engine:
         self.aug = torch.empty(Sl, _ffi.APH_AUG_STRIDE, **f32) if self.geometric else None
         self.tmp = torch.empty(2 * Sl * 3 * self.size * self.size, **f32) if self.geometric else None
 
+    def state(self):
+        return self._state
+
+    @property
+    def step_count(self):
+        return self._state['step'][0]
+
     def set_targets(self, targets):
-        self.targets = torch.cat([t.reshape(1, -1).float() for t, _ in targets], 0).to(self.dev).contiguous()
-        self.coef = [float(c) for _, c in targets]
+        """targets: list of (embedding, coef); an embedding of shape [1,D] is compared with every cut, one of shape
+        [S,D] pairs row s with cut s (the reference-image term, clip_fft.py:216,267).  Broadcast ones go first."""
+        bro = [(t, c) for t, c in targets if t.reshape(-1, t.shape[-1]).shape[0] == 1]
+        per = [(t, c) for t, c in targets if t.reshape(-1, t.shape[-1]).shape[0] != 1]
+        for t, _ in per:
+            if t.shape[0] != self.S:
+                raise ValueError('per-cut target has %d rows, expected %d' % (t.shape[0], self.S))
+        self.n_broadcast = len(bro)
+        self.targets = torch.cat([t.reshape(-1, t.shape[-1]).float().to(self.dev) for t, _ in bro + per], 0).contiguous()
+        self.coef = [float(c) for _, c in bro + per]
         self.dcoef = torch.tensor(self.coef, dtype=torch.float32, device=self.dev)
         self.hcoef = _ffi.floats(self.coef)
 
@@ -111,7 +132,8 @@ class Engine:
             L.call('aph_synth_fft_fwd', self.plan.handle, ops.ptr(self.params), ops.ptr(self.scale), ops.ptr(shift), float(contrast),
                    _ffi.floats(self.cc), int(self.decorrelate), ops.ptr(self.raw), ops.ptr(self.rgb), st)
         else:
-            L.call('aph_synth_spatial_fwd', self.plan.handle, ops.ptr(self.params), float(contrast), 0.0, _ffi.floats(self.cc),
+            self.spatial = self.dwt.forward(self.params) if self.kind == 'dwt' else self.params
+            L.call('aph_synth_spatial_fwd', self.plan.handle, ops.ptr(self.spatial), float(contrast), 0.0, _ffi.floats(self.cc),
                    int(self.decorrelate), ops.ptr(self.rgb), st)
         return self.rgb
 
@@ -121,9 +143,9 @@ class Engine:
             table, augs = self.draw()
         L, st = self.lib, ops._stream(self.params)
         Sl = self.S_loc
-        self.step_count += 1
+        self._state['step'][0] += 1
         lr = self.lr if lr is None else lr
-        hy = ops.adam_hyper(self.step_count, lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
+        hy = ops.adam_hyper(self._state['step'][0], lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
         self.hyper.copy_(torch.tensor(hy, dtype=torch.float32), non_blocking=True)
         if Sl > 0:
             self.table.copy_(torch.from_numpy(np.ascontiguousarray(table[self.lo:self.hi])), non_blocking=True)
@@ -137,7 +159,7 @@ class Engine:
                    ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
             self.visual._forward_patches(self.patches, Sl, self.enc)
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
-                   len(self.coef), _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
+                   len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
             # backward
             self.visual.handle.backward(self.genc, Sl, self.gpatch, 1.0 / LOSS_SCALE)
@@ -149,6 +171,10 @@ class Engine:
         if self.kind == 'fft':
             L.call('aph_synth_fft_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.raw), ops.ptr(self.scale),
                    1.0, cc, int(self.decorrelate), ops.ptr(self.grad), st)
+        elif self.kind == 'dwt':
+            L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.spatial), 1.0, 0.0, cc,
+                   int(self.decorrelate), ops.ptr(self.raw), st)            # d raw (reuses the raw buffer)
+            self.dwt.backward(self.raw, self.grad)
         else:
             L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, 0.0, cc,
                    int(self.decorrelate), ops.ptr(self.grad), st)

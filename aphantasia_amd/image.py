@@ -212,6 +212,92 @@ def pixel_image(shape, resume=None, sd=1., *noargs, **nokwargs):
     return [image_t], PixelImage(image_t), size
 
 
+class _SynthDWT(torch.autograd.Function):
+    """dwt_image.inner (+ to_valid_rgb when `cc` is given): inverse DWT levels + K3/K4 (csrc/dwt.hip, synth.hip)"""
+
+    @staticmethod
+    def forward(ctx, gen, contrast, cc, decorrelate, to_rgb, *Ys):
+        flat = gen.flat_for(Ys)
+        raw = gen.synth.forward(flat)
+        if to_rgb:
+            out = ops.synth_spatial_fwd(gen.plan, raw, contrast, 0.0, cc, decorrelate)
+        else:
+            out = ops.synth_spatial_fwd(gen.plan, raw, contrast, 0.0, None, False)      # still needs the std
+        stats = torch.empty(2, dtype=torch.float32, device=raw.device)
+        gen.plan.lib.call('aph_synth_stats', gen.plan.handle, ops.ptr(stats), ops._stream(raw))
+        ctx.gen, ctx.args, ctx.to_rgb = gen, (contrast, cc, decorrelate), to_rgb
+        if not to_rgb:
+            out = raw * (contrast / stats[1])
+        ctx.save_for_backward(raw.clone(), out, stats)
+        return out.unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, out, stats = ctx.saved_tensors
+        gen = ctx.gen
+        contrast, cc, decorrelate = ctx.args
+        g = g.reshape(raw.shape).contiguous().float()
+        if ctx.to_rgb:
+            gen.plan.lib.call('aph_synth_set_stats', gen.plan.handle, ops.ptr(stats), ops._stream(raw))
+            d_raw = ops.synth_spatial_bwd(gen.plan, g, out, raw, contrast, 0.0, cc, decorrelate)
+        else:
+            n, s, mu = raw.numel(), stats[1], stats[0]
+            sgx = (g.double() * raw.double()).sum().float()
+            d_raw = (contrast / s) * g - (contrast * sgx / (s ** 3 * (n - 1))) * (raw - mu)
+        grad = torch.empty(gen.synth.numel, dtype=torch.float32, device=raw.device)
+        gen.synth.backward(d_raw.contiguous(), grad)
+        return (None, None, None, None, None, *[v.clone() for v in gen.synth.views(grad)])
+
+
+class DWTImage:
+    """dwt_image's closure (image.py:64-69).  `Ys` are leaf views into one flat coefficient buffer."""
+
+    def __init__(self, h, w, wave, sharp, device):
+        from .dwt import DWTSynth
+        self.synth = DWTSynth(h, w, wave, sharp, device)
+        self.flat = torch.empty(self.synth.numel, dtype=torch.float32, device=device)
+        self.Ys = None
+        self.plan = ops.SynthPlan(3, self.synth.H, self.synth.W)
+
+    def flat_for(self, Ys):
+        """the flat buffer if Ys are (still) our views, else a packed copy"""
+        views = self.synth.views(self.flat)
+        if all(y.data_ptr() == v.data_ptr() for y, v in zip(Ys, views)):
+            return self.flat
+        return torch.cat([y.detach().reshape(-1).float() for y in Ys]).contiguous()
+
+    def __call__(self, shift=None, contrast=1.):
+        return _SynthDWT.apply(self, float(contrast), None, False, False, *self.Ys)
+
+    def rgb(self, cc, decorrelate, shift=None, contrast=1.):
+        return _SynthDWT.apply(self, float(contrast), cc, decorrelate, True, *self.Ys)
+
+
+def dwt_image(shape, wave='coif2', sharp=0.3, colors=1., resume=None):
+    """image.py:61-71 -> (Ys, image_f, size).  Random init draws randn per tensor on the CPU generator in the
+    reference's order (Yl, then detail levels finest first; image.py:41-42).  `resume`: list of tensors or a .pt file."""
+    h, w = shape[2:]
+    gen = DWTImage(h, w, wave, sharp, _device())
+    views = gen.synth.views(gen.flat)
+    if resume is None:
+        init = [torch.randn(*v.shape) for v in views]
+    else:
+        if isinstance(resume, str):
+            if not os.path.isfile(resume):
+                print(' Snapshot not found:', resume)
+                exit()
+            if os.path.splitext(resume)[1].lower()[1:] in ['jpg', 'png', 'tif', 'bmp']:
+                raise NotImplementedError('resuming the DWT parameters from an image file (img2dwt) is not implemented')
+            resume = torch.load(resume)
+        init = [y.detach().float() for y in resume]
+        if [tuple(y.shape) for y in init] != [tuple(v.shape) for v in views]:
+            raise ValueError('snapshot coefficient shapes do not match a %dx%d %s transform' % (w, h, wave))
+    for v, y in zip(views, init):
+        v.copy_(y)
+    gen.Ys = [v.requires_grad_(True) for v in views]
+    return gen.Ys, gen, None
+
+
 def to_valid_rgb(image_f, colors=1., decorrelate=True):
     """image.py:14-29: returns inner(*args, **kwargs) -> sigmoid(colour-decorrelated image) in (0,1)."""
     cc = colcorr_t(colors).flatten().tolist()

@@ -209,18 +209,24 @@ def gemm_f16(A, Bt, lib=None):
 
 
 # ------------------------------------------------------------------ loss / optimiser
-def sim_loss(enc, targets, coef, sim_type='mix', denom=None, gscale=1.0, lib=None):
-    """-> (loss [1] device tensor, genc [S,D]);  targets [T,D], coef: python floats (sign*weight)"""
+def sim_loss(enc, targets, coef, sim_type='mix', denom=None, gscale=1.0, lib=None, per_sample=None, s_total=None, s_offset=0):
+    """-> (loss [1] device tensor, genc [S,D]);  targets [T,D] broadcast embeddings, per_sample: optional
+    [Tp, s_total, D] per-cut targets (coef lists broadcast ones first), coef: python floats (sign*weight)"""
     L = _L(lib, enc, targets)
     _chk(enc, torch.float32, 'enc'); _chk(targets, torch.float32, 'targets')
     S, D = enc.shape
-    T = targets.shape[0]
+    nb = 0 if targets is None else targets.shape[0]
+    T = nb + (0 if per_sample is None else per_sample.shape[0])
+    if per_sample is not None:
+        s_total = per_sample.shape[1] if s_total is None else s_total
+        flat = per_sample.reshape(-1, D).float()
+        targets = flat.contiguous() if targets is None else torch.cat([targets, flat], 0).contiguous()
     code = _ffi.SIM_TYPES.get(sim_type if sim_type in _ffi.SIM_TYPES else _sim_key(sim_type))
     dcoef = torch.tensor(list(coef), dtype=torch.float32).to(enc.device)
     ws = torch.empty(S * (T + 2), dtype=torch.float32, device=enc.device)
     loss = torch.empty(1, dtype=torch.float32, device=enc.device)
     genc = torch.empty_like(enc)
-    L.call('aph_sim_loss', ptr(enc), S, D, ptr(targets), ptr(dcoef), floats(list(coef)), T, code,
+    L.call('aph_sim_loss', ptr(enc), S, D, ptr(targets), ptr(dcoef), floats(list(coef)), T, nb, int(s_total or S), int(s_offset), code,
            float(S if denom is None else denom), float(gscale), ptr(ws), ptr(loss), ptr(genc), _stream(enc))
     return loss, genc
 

@@ -141,7 +141,10 @@ def pad_up_to(x, size, type='centr'):
 class _SimLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, target, sim_type):
-        loss, genc = ops.sim_loss(enc.contiguous().float(), target.contiguous().float(), [1.0], sim_type)
+        if target.shape[0] == 1:
+            loss, genc = ops.sim_loss(enc.contiguous().float(), target.contiguous().float(), [1.0], sim_type)
+        else:       # pairwise form: row s of `target` against cut s
+            loss, genc = ops.sim_loss(enc.contiguous().float(), None, [1.0], sim_type, per_sample=target.float()[None].contiguous())
         ctx.save_for_backward(genc)
         return loss.reshape(())
 
@@ -159,7 +162,8 @@ def sim_func(v1, v2, type=None):
         a = torch.nn.functional.normalize(v1, dim=-1)
         b = torch.nn.functional.normalize(v2, dim=-1)
         return (a - b).norm(dim=-1).div(2).arcsin().pow(2).mul(2)
-    if v1.dim() == 2 and v1.shape[0] == 1 and v2.dim() == 2 and not v1.requires_grad and v2.is_cuda:
+    if v1.dim() == 2 and v2.dim() == 2 and v1.shape[0] in (1, v2.shape[0]) and not v1.requires_grad and v2.is_cuda \
+            and not (v1.shape[0] != 1 and type and 'dot' in type):
         return _SimLoss.apply(v2, v1.to(v2.device), type)
     if v2.dim() == 2 and v2.shape[0] == 1 and v1.dim() == 2 and not v2.requires_grad and v1.is_cuda and not (type and 'dot' in type):
         return _SimLoss.apply(v1, v2.to(v1.device), type)

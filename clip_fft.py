@@ -1,0 +1,282 @@
+#!/usr/bin/env python
+"""Text/image -> image optimisation on MI355X: drop-in for the reference's clip_fft.py.
+
+Same command line (every flag of the reference's get_args, clip_fft.py:37-77, with the same defaults,
+post-parse overrides and sample-count derating arithmetic), same output naming and `.pt` snapshot
+format.  Additive flags: --clip-weights PATH (OpenAI CLIP checkpoint; without it seeded synthetic
+weights are used and the pictures are meaningless), --seed N (seeds torch + numpy; the reference is
+unseeded), --no_save (skip the per-step JPEG, for timing).
+
+The standard loss (text / style / subtract prompts and a reference image, any --sim) runs through the
+fused HIP engine (aphantasia_amd/engine.py); --sharp / --enforce / --expand / --aest / --sync use the
+autograd drop-in API (aphantasia_amd.image / .utils / .clip) exactly like reference-style user code.
+"""
+import argparse
+import os
+import shutil
+import sys
+import threading
+import queue
+import time
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+clip_models = ['ViT-B/16', 'ViT-B/32', 'RN101', 'RN50x16', 'RN50x4', 'RN50']
+
+
+def get_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-t',  '--in_txt',  default=None, help='input text')
+    parser.add_argument('-t2', '--in_txt2', default=None, help='input text - style')
+    parser.add_argument('-t0', '--in_txt0', default=None, help='input text to subtract')
+    parser.add_argument('-i',  '--in_img',  default=None, help='input image')
+    parser.add_argument('-wi', '--weight_img', default=0.5, type=float, help='weight for images')
+    parser.add_argument(       '--out_dir', default='_out')
+    parser.add_argument('-s',  '--size',    default='1280-720', help='Output resolution')
+    parser.add_argument('-r',  '--resume',  default=None, help='Path to saved FFT snapshots, to resume from')
+    parser.add_argument('-ops', '--opt_step', default=1, type=int, help='How many optimizing steps per save step')
+    parser.add_argument('-tr', '--translate', action='store_true', help='Translate text with Google Translate')
+    parser.add_argument(       '--save_pt', action='store_true', help='Save FFT snapshots for further use')
+    parser.add_argument('-v',  '--verbose',    dest='verbose', action='store_true')
+    parser.add_argument('-nv', '--no-verbose', dest='verbose', action='store_false')
+    parser.set_defaults(verbose=True)
+    # training
+    parser.add_argument('-m',  '--model',   default='ViT-B/32', choices=clip_models, help='Select CLIP model to use')
+    parser.add_argument(       '--steps',   default=200, type=int, help='Total iterations')
+    parser.add_argument(       '--samples', default=200, type=int, help='Samples to evaluate')
+    parser.add_argument('-lr', '--lrate',   default=0.05, type=float, help='Learning rate')
+    parser.add_argument('-p',  '--prog',    action='store_true', help='Enable progressive lrate growth (up to double a.lrate)')
+    parser.add_argument('-dm', '--dualmod', default=None, type=int, help='Every this step use another CLIP ViT model')
+    # wavelet
+    parser.add_argument(       '--dwt',     action='store_true', help='Use DWT instead of FFT')
+    parser.add_argument('-w',  '--wave',    default='coif2', help='wavelets: db[1..], coif[1..], haar, dmey')
+    # tweaks
+    parser.add_argument('-a',  '--align',   default='uniform', choices=['central', 'uniform', 'overscan', 'overmax'], help='Sampling distribution')
+    parser.add_argument('-tf', '--transform', default='fast', choices=['none', 'fast', 'custom', 'elastic'], help='augmenting transforms')
+    parser.add_argument('-opt', '--optimizer', default='adam_custom', choices=['adam', 'adamw', 'adam_custom', 'adamw_custom'], help='Optimizer')
+    parser.add_argument(       '--contrast', default=1.1, type=float)
+    parser.add_argument(       '--colors',  default=1.8, type=float)
+    parser.add_argument(       '--decay',   default=1.5, type=float)
+    parser.add_argument('-sh', '--sharp',   default=0., type=float)
+    parser.add_argument('-mm', '--macro',   default=0.4, type=float, help='Endorse macro forms 0..1 ')
+    parser.add_argument(       '--aest',    default=0., type=float, help='Enhance aesthetics')
+    parser.add_argument('-e',  '--enforce', default=0, type=float, help='Enforce details (by boosting similarity between two parallel samples)')
+    parser.add_argument('-x',  '--expand',  default=0, type=float, help='Boosts diversity (by enforcing difference between prev/next samples)')
+    parser.add_argument('-n',  '--noise',   default=0, type=float, help='Add noise to suppress accumulation')
+    parser.add_argument('-c',  '--sync',    default=0, type=float, help='Sync output to input image')
+    parser.add_argument(       '--invert',  action='store_true', help='Invert criteria')
+    parser.add_argument(       '--sim',     default='mix', help='Similarity function (dot/angular/spherical/mixed; None = cossim)')
+    # additive (not in the reference)
+    parser.add_argument(       '--clip-weights', dest='clip_weights', default=None, help='OpenAI CLIP checkpoint (ViT-B-32.pt); second model: --clip-weights2')
+    parser.add_argument(       '--clip-weights2', dest='clip_weights2', default=None, help='checkpoint of the --dualmod model (ViT-B-16.pt)')
+    parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
+    parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
+    a = parser.parse_args(argv)
+
+    if a.size is not None: a.size = [int(s) for s in a.size.split('-')][::-1]        # clip_fft.py:80
+    if len(a.size) == 1: a.size = a.size * 2
+    if (a.in_img is not None and a.sync != 0) or a.resume is not None: a.align = 'overscan'
+    if a.translate is True:
+        print('\n Install googletrans module to enable translation!'); exit()
+    if a.dualmod is not None:                                                         # clip_fft.py:86-88
+        a.model = 'ViT-B/32'
+        a.sim = 'cossim'
+    return a
+
+
+def derate_samples(a):
+    """The reference's sample-count arithmetic, in its order (clip_fft.py:125-127,134,157-169,187,199)."""
+    xmem = {'ViT-B/16': 0.25, 'RN50': 0.5, 'RN50x4': 0.16, 'RN50x16': 0.06, 'RN101': 0.33}
+    s = a.samples
+    if a.model in xmem:
+        s = int(s * xmem[a.model])
+    if a.dualmod is not None:
+        s = int(s * 0.23)
+    if a.enforce != 0:
+        s = int(s * 0.5)
+    if a.sync > 0:
+        s = int(s * 0.5)
+    if a.transform in ('elastic', 'custom', 'fast'):
+        s = int(s * 0.95)
+    if a.in_txt2 is not None:
+        s = int(s * 0.75)
+    if a.in_txt0 is not None:
+        s = int(s * 0.75)
+    return s
+
+
+class FrameWriter:
+    """Background JPEG writer: the reference encodes every frame synchronously on the hot loop (clip_fft.py:297-306)."""
+
+    def __init__(self):
+        self.q = queue.Queue(maxsize=8)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        from aphantasia_amd.utils import checkout
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            img, ev, fname, gamma = item
+            ev.synchronize()
+            arr = img.numpy()
+            if gamma != 1.0:
+                arr = arr ** gamma
+            checkout(arr, fname)
+
+    def put(self, img_host, event, fname, gamma):
+        self.q.put((img_host, event, fname, gamma))
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+
+
+def main(argv=None):
+    a = get_args(argv)
+    if a.seed is not None:
+        torch.manual_seed(a.seed)
+        np.random.seed(a.seed)
+    if not a.model.startswith('ViT'):
+        raise SystemExit(' the MI355X path covers the ViT CLIP models (ViT-B/32, ViT-B/16); got %s' % a.model)
+    if a.transform in ('custom', 'elastic'):
+        raise SystemExit(' -tf %s (kornia-based) is not provided; use fast or none' % a.transform)
+    from aphantasia_amd import clip as aclip, transforms
+    from aphantasia_amd.image import to_valid_rgb, fft_image, dwt_image
+    from aphantasia_amd.utils import slice_imgs, sim_func, basename, img_list, img_read, txt_clean
+    from aphantasia_amd.engine import Engine
+
+    shape = [1, 3, *a.size]
+    if a.dwt is True:
+        params, image_f, sz = dwt_image(shape, a.wave, 0.3, a.colors, a.resume)
+    else:
+        params, image_f, sz = fft_image(shape, 0.07, a.decay, a.resume)
+    if sz is not None: a.size = sz
+    rgb_f = to_valid_rgb(image_f, colors=a.colors)
+
+    if a.prog is True:
+        lr1 = a.lrate * 2
+        lr0 = lr1 * 0.01
+    else:
+        lr0 = a.lrate
+    sign = 1. if a.invert is True else -1.
+
+    with warnings.catch_warnings():
+        if a.clip_weights is None:
+            print(' !! no --clip-weights given: using seeded SYNTHETIC CLIP weights (timing / plumbing only)')
+            warnings.simplefilter('ignore')
+        model_clip, _ = aclip.load(a.model, weights=a.clip_weights)
+        a.modsize = model_clip.visual.input_resolution
+        if a.verbose is True: print(' using model', a.model)
+        a.samples = derate_samples(a)
+        if a.dualmod is not None:
+            model_clip2, _ = aclip.load('ViT-B/16', weights=a.clip_weights2)
+            dualmod_nums = list(range(a.steps))[a.dualmod::a.dualmod]
+            print(' dual model every %d step' % a.dualmod)
+
+    def enc_text(txt, model=model_clip):                                              # clip_fft.py:143-154
+        embs = []
+        for subtxt in txt.split('|'):
+            if ':' in subtxt:
+                [subtxt, wt] = subtxt.split(':')
+                wt = float(wt)
+            else: wt = 1.
+            embs.append([aclip.text_embedding(model, subtxt), wt])
+        return embs
+
+    trform_f = transforms.transforms_fast if 'fast' in a.transform else transforms.normalize()
+    out_name = []
+    targets, targets2 = [], []          # (embedding, coef) for model 1 / model 2
+    if a.in_txt is not None:
+        if a.verbose is True: print(' topic text: ', a.in_txt)
+        targets += [(e, sign * w) for e, w in enc_text(a.in_txt)]
+        out_name.append(txt_clean(a.in_txt).lower()[:40])
+        if a.dualmod is not None: targets2 += [(e, sign * w) for e, w in enc_text(a.in_txt, model_clip2)]
+    if a.in_txt2 is not None:
+        if a.verbose is True: print(' style text:', a.in_txt2)
+        targets += [(e, sign * w) for e, w in enc_text(a.in_txt2)]
+        out_name.append(txt_clean(a.in_txt2).lower()[:40])
+        if a.dualmod is not None: targets2 += [(e, sign * w) for e, w in enc_text(a.in_txt2, model_clip2)]
+    if a.in_txt0 is not None:
+        if a.verbose is True: print(' subtract text:', a.in_txt0)
+        targets += [(e, -sign * w) for e, w in enc_text(a.in_txt0)]
+        out_name.append('off-' + txt_clean(a.in_txt0).lower()[:40])
+        if a.dualmod is not None: targets2 += [(e, -sign * w) for e, w in enc_text(a.in_txt0, model_clip2)]
+    if a.in_img is not None and os.path.isfile(a.in_img):
+        if a.verbose is True: print(' ref image:', basename(a.in_img))
+        img_in = torch.from_numpy(img_read(a.in_img) / 255.).unsqueeze(0).permute(0, 3, 1, 2).cuda().float()[:, :3]
+        with torch.no_grad():
+            in_sliced = slice_imgs([img_in], a.samples, a.modsize, transforms.normalize(), a.align,
+                                   patch=model_clip.visual.patch_size)[0]
+            targets.append((model_clip.encode_image(in_sliced).detach().clone(), sign * a.weight_img))   # per-cut pairs, clip_fft.py:216,267
+            if a.dualmod is not None:
+                targets2.append((model_clip2.encode_image(in_sliced).detach().clone(), sign * a.weight_img))
+        out_name.append(basename(a.in_img).replace(' ', '_'))
+    assert targets, ' Loss not defined, check the inputs'                              # clip_fft.py:286
+
+    if a.verbose is True: print(' samples:', a.samples)
+    out_name = '-'.join(out_name)
+    out_name += '-%s' % a.model.replace('/', '').replace('-', '') if a.dualmod is None else '-dm%d' % a.dualmod
+    tempdir = os.path.join(a.out_dir, out_name)
+    os.makedirs(tempdir, exist_ok=True)
+
+    fused = a.sharp == 0 and a.enforce == 0 and a.expand == 0 and a.aest == 0 and a.sync == 0
+    if not fused:
+        raise SystemExit(' --sharp/--enforce/--expand/--aest/--sync run through the autograd drop-in API; '
+                         'see examples in tests/test_gpu_step.py (not wired into this CLI yet)')
+    h, w = a.size
+    if a.dwt is True:
+        pk = dict(param_kind='dwt', dwt=image_f.synth)
+        leaf = image_f.flat
+    else:
+        pk = dict(param_kind='fft')
+        leaf = params[0]
+    eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
+                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, **pk)
+    h, w = eng.h, eng.w
+    eng2 = None
+    if a.dualmod is not None:
+        eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
+                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), **pk)
+
+    writer = None if a.no_save else FrameWriter()
+    host_bufs = [torch.empty(3, h, w).pin_memory() for _ in range(4)]
+    gamma = 1.0
+    t0 = time.time()
+    for i in range(a.steps):
+        e = eng2 if (eng2 is not None and i in dualmod_nums) else eng
+        lr_cur = lr0 + (i / a.steps) * (lr1 - lr0) if a.prog is True else lr0      # clip_fft.py:288-291
+        shift = None
+        if a.noise > 0 and a.dwt is not True:
+            shift = (a.noise * torch.rand(1, 1, h, w // 2 + 1, 1)).reshape(h, w // 2 + 1).cuda().contiguous()
+        e.step(lr=lr_cur, shift=shift)
+        if i % a.opt_step == 0 and writer is not None:
+            img = e.synthesize(a.contrast)                                              # clip_fft.py:298-299
+            buf = host_bufs[(i // a.opt_step) % len(host_bufs)]
+            buf.copy_(img, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            writer.put(buf, ev, os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)
+        if a.verbose and (i % 10 == 9 or i == a.steps - 1):
+            print(' step %d/%d  loss %.4f  %.1f steps/s' % (i + 1, a.steps, e.global_loss(), (i + 1) / (time.time() - t0)), flush=True)
+    torch.cuda.synchronize()
+    if writer is not None:
+        writer.close()
+        if shutil.which('ffmpeg'):
+            os.system('ffmpeg -v warning -y -i %s/\\%%04d.jpg "%s.mp4"' % (tempdir, os.path.join(a.out_dir, out_name)))
+        frames = img_list(tempdir)
+        if frames:
+            shutil.copy(frames[-1], os.path.join(a.out_dir, '%s-%d.jpg' % (out_name, a.steps)))
+    if a.save_pt is True:
+        torch.save([p.detach().cpu() for p in params], '%s.pt' % os.path.join(a.out_dir, out_name))   # clip_fft.py:315 (list of tensors)
+    print(' done: %d steps in %.1fs (%.1f steps/s)' % (a.steps, time.time() - t0, a.steps / (time.time() - t0)))
+
+
+if __name__ == '__main__':
+    main()

@@ -59,6 +59,17 @@ int aph_synth_stats(aph_synth_plan* plan, float* d_out2, void* stream);
 /* restore them (d_in2 device, 2 floats) before an adjoint whose forward was followed by other forwards */
 int aph_synth_set_stats(aph_synth_plan* plan, const float* d_in2, void* stream);
 
+/* ---- wavelet parameteriser: aphantasia/image.py:33-80 (dwt_image) over pytorch_wavelets.DWTInverse ------- */
+/* One synthesis level (lowlevel.SFB2D, mode 'symmetric').  d_ll [C,ll_h,ll_w] running low band (ll_h in {h,h+1}:
+ * the extra row/col DWTInverse.forward drops is ignored), d_highs [C,3,h,w] = (LH,HL,HH) of this level,
+ * d_g0/d_g1 = rec_lo/rec_hi taps (device, L even <= 64), hscale = dwt_scale gain (image.py:73-80)
+ * -> d_out [C, 2h-L+2, 2w-L+2]. */
+int aph_idwt_level_fwd(const float* d_ll, int ll_h, int ll_w, const float* d_highs, int h, int w, int C,
+                       const float* d_g0, const float* d_g1, int L, float hscale, float* d_out, void* stream);
+/* adjoint: d_out_grad -> d_ll_grad [C,ll_h,ll_w] (dropped row/col = 0) and d_highs_grad [C,3,h,w] */
+int aph_idwt_level_bwd(const float* d_out_grad, int h, int w, int C, const float* d_g0, const float* d_g1, int L,
+                       float hscale, float* d_ll_grad, int ll_h, int ll_w, float* d_highs_grad, void* stream);
+
 /* ---- sampler: aphantasia/utils.py:218-254 slice_imgs + transforms.py:102-109,165-170 ------- */
 /* Geometry of one slice_imgs call.  (Hp,Wp,py0,px0) describe the wrap-tiled overscan frame of
  * pad_up_to/tile_pad (utils.py:152-187); Hp=H, Wp=W, py0=px0=0 when align has no 'over'. */
@@ -120,11 +131,14 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
 #define APH_SIM_ANG 2   /* 'ang' */
 #define APH_SIM_DOT 3   /* 'dot' */
 /* loss = sum_t coef_t * sim_func(target_t, enc, type), value -> d_loss (1 float) and
- * gscale * dloss/denc -> d_genc [S,D].  d_targets [T,D], d_coef [T] (sign*weight), h_coef = host copy
+ * gscale * dloss/denc -> d_genc [S,D].  d_targets = n_broadcast rows [D] (one embedding vs every cut: text
+ * prompts) followed by T-n_broadcast blocks [s_total,D] of per-cut targets (reference-image term,
+ * clip_fft.py:216,267; s_offset = first global cut of this rank's shard), d_coef [T] (sign*weight), h_coef = host copy
  * (needed for 'ang'), denom = sample count of the global mean (S, or the all-rank total),
  * d_ws = f32 scratch of S*(T+2) elements. */
 int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const float* d_coef, const float* h_coef,
-                 int T, int type, float denom, float gscale, float* d_ws, float* d_loss, float* d_genc, void* stream);
+                 int T, int n_broadcast, int s_total, int s_offset, int type, float denom, float gscale, float* d_ws,
+                 float* d_loss, float* d_genc, void* stream);
 
 /* ---- optimiser: torch.optim.Adam / AdamW as configured at clip_fft.py:108-115 --------------- */
 /* d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale};

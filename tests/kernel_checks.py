@@ -76,6 +76,31 @@ def check_synth_spatial(lib, dev, h=24, w=40):
         assert (d.cpu() - img.grad[0]).abs().max().item() < 2e-5 * img.grad.abs().max().item() + 1e-7
 
 
+def check_dwt(lib, dev, wave, h, w, sharp=0.3, colors=1.5, contrast=1.1):
+    """dwt_image + to_valid_rgb: inverse DWT levels, std, colour, sigmoid and the full adjoint vs the oracle"""
+    from aphantasia_amd.dwt import DWTSynth
+    from oracle import dwt_ref
+    seed_all(8)
+    Ys = [y.requires_grad_(True) for y in dwt_ref.init_params([1, 3, h, w], wave)]
+    cc_t = R.colcorr_t(colors)
+    want = dwt_ref.synth_dwt(Ys, wave, cc_t, sharp, contrast)
+    gw = torch.randn(want.shape, generator=torch.Generator().manual_seed(3))
+    (want * gw).sum().backward()
+    syn = DWTSynth(h, w, wave, sharp, dev, lib=lib)
+    assert [tuple(y.shape) for y in Ys] == list(syn.shapes)
+    flat = torch.cat([y.detach().reshape(-1) for y in Ys]).to(dev).contiguous()
+    raw = syn.forward(flat)
+    assert tuple(raw.shape[1:]) == tuple(want.shape[2:])
+    plan = ops.SynthPlan(3, syn.H, syn.W, lib=lib)
+    rgb = ops.synth_spatial_fwd(plan, raw, contrast, 0.0, cc_t.flatten().tolist(), True, lib=lib)
+    assert (rgb.cpu() - want.detach()[0]).abs().max().item() < 5e-6
+    d_raw = ops.synth_spatial_bwd(plan, gw[0].to(dev).contiguous(), rgb, raw, contrast, 0.0, cc_t.flatten().tolist(), True, lib=lib)
+    grad = torch.empty_like(flat)
+    syn.backward(d_raw, grad)
+    ref = torch.cat([y.grad.reshape(-1) for y in Ys])
+    assert (grad.cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
 def check_sampler_golden(lib, dev, g, align):
     img = torch.from_numpy(g['img'])
     seed_all(7)
@@ -142,6 +167,26 @@ def check_sim_loss(lib, dev, g):
     loss, genc = ops.sim_loss(v2.to(dev), tg.to(dev), [-1.0, 0.5], 'mix', gscale=8.0, lib=lib)
     assert abs(loss.item() - want.item()) < 1e-6
     assert np.allclose(genc.cpu().numpy() / 8.0, x.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
+def check_sim_loss_per_cut(lib, dev):
+    """reference-image term: per-cut target rows (clip_fft.py:267) mixed with a broadcast prompt, sharded call"""
+    g = torch.Generator().manual_seed(6)
+    S, Dm = 7, 64
+    enc = torch.randn(S, Dm, generator=g)
+    txt = torch.randn(1, Dm, generator=g)
+    ref = torch.randn(S, Dm, generator=g)
+    for t in ['mix', None, 'ang']:
+        x = enc.clone().requires_grad_(True)
+        want = -1.0 * R.sim_func(txt, x, t) - 0.5 * R.sim_func(ref, x, t)
+        want.backward()
+        loss, genc = ops.sim_loss(enc.to(dev), txt.to(dev), [-1.0, -0.5], t, per_sample=ref[None].to(dev), lib=lib)
+        assert abs(loss.item() - want.item()) < 2e-6, t
+        assert np.allclose(genc.cpu().numpy(), x.grad.numpy(), rtol=3e-4, atol=3e-7), t
+        # a shard of cuts 2..4 with the global denominator: gradients are the matching rows, losses add up
+        l2, g2 = ops.sim_loss(enc[2:5].contiguous().to(dev), txt.to(dev), [-1.0, -0.5], t, denom=S, per_sample=ref[None].to(dev),
+                              s_total=S, s_offset=2, lib=lib)
+        assert np.allclose(g2.cpu().numpy(), x.grad.numpy()[2:5], rtol=3e-4, atol=3e-7), t
 
 
 def check_adam(lib, dev, n=5000):

@@ -30,6 +30,11 @@ def test_synth_oracle_shift_and_odd_radix(emu):
     K.check_synth_vs_oracle(emu, 'cpu', 21, 26, 1.1)      # radix 3,7 / 2,13: generic butterflies
 
 
+def test_dwt(emu):
+    K.check_dwt(emu, 'cpu', 'db3', 45, 70)          # odd sizes: the dropped row/col path
+    K.check_dwt(emu, 'cpu', 'coif2', 64, 96)
+
+
 def test_synth_spatial(emu):
     K.check_synth_spatial(emu, 'cpu')
 
@@ -51,6 +56,7 @@ def test_sampler_augment(emu):
 
 def test_sim_loss(emu, golden):
     K.check_sim_loss(emu, 'cpu', golden('sim.npz'))
+    K.check_sim_loss_per_cut(emu, 'cpu')
 
 
 def test_adam(emu):

@@ -24,6 +24,13 @@ def test_synth_oracle_full_size():
     K.check_synth_vs_oracle(None, DEV, 720, 1280, 1.0)
 
 
+def test_dwt():
+    K.check_dwt(None, DEV, 'db3', 45, 70)
+    K.check_dwt(None, DEV, 'coif2', 64, 96)
+    K.check_dwt(None, DEV, 'haar', 96, 128)
+    K.check_dwt(None, DEV, 'db3', 540, 960)          # quarter of BASELINE configs[3] (the CPU oracle stays quick)
+
+
 def test_synth_spatial():
     K.check_synth_spatial(None, DEV)
     K.check_synth_spatial(None, DEV, 720, 1280)
@@ -52,6 +59,7 @@ def test_sampler_augment():
 
 def test_sim_loss(golden):
     K.check_sim_loss(None, DEV, golden('sim.npz'))
+    K.check_sim_loss_per_cut(None, DEV)
 
 
 def test_adam():

@@ -161,3 +161,34 @@ def test_full_size_properties(model):
     fd = (((rp - rm).double() / (2 * eps)) * gw.double()).sum().item()
     an = (grad.double() * d.double()).sum().item()
     assert abs(fd - an) < 2e-2 * abs(an), (fd, an)
+
+
+def test_dwt_and_pixel_engines_vs_autograd_api(model):
+    """dwt_image / pixel_image through the fused engine == the same step through the drop-in autograd API"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd.image import dwt_image, pixel_image, to_valid_rgb
+    from aphantasia_amd.utils import slice_imgs, sim_func
+    from aphantasia_amd import transforms
+    h, w, S = 256, 320, 4
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    for kind in ('dwt', 'pixel'):
+        seed_all(0)
+        if kind == 'dwt':
+            params, image_f, _ = dwt_image([1, 3, h, w], 'db3', 0.3, 1.8, None)
+        else:
+            params, image_f, _ = pixel_image([1, 3, h, w], sd=1.0)
+        rgb_f = to_valid_rgb(image_f, colors=1.8)
+        seed_all(5)
+        cuts = slice_imgs([rgb_f()], S, 224, transforms.normalize(), 'uniform', 0.4)[0]
+        loss = -1.0 * sim_func(target.to(DEV), model.encode_image(cuts), 'mix')
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in params])
+        if kind == 'dwt':
+            eng = Engine(image_f.flat.detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(),
+                         param_kind='dwt', dwt=image_f.synth)
+        else:
+            eng = Engine(params[0].detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(), param_kind='pixel')
+        seed_all(5)
+        l2 = float(eng.step())
+        assert abs(l2 - float(loss)) < 1e-5, kind
+        assert (eng.grad.reshape(-1) - grads).abs().max().item() < 1e-4 * grads.abs().max().item() + 1e-9, kind
