@@ -113,6 +113,17 @@ __device__ __forceinline__ void wait_vm_barrier() {
 #endif
 }
 
+// Lanes of one wave exchanging data through LDS: the hardware runs a wave's LDS instructions in order, so no
+// s_barrier is needed -- this only pins the compiler's order (and lets the host interpreter, whose lanes are
+// separate fibers, rendezvous).
+__device__ __forceinline__ void wave_lds_fence() {
+#ifdef APH_EMU
+  emu::wave_barrier();
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // all of this wave's LDS reads have returned
 __device__ __forceinline__ void wait_lgkm0() {
 #ifndef APH_EMU

@@ -255,8 +255,8 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
     vgemm(v, v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
     vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, M, D, 4 * D, EpiResidual{x_next, l.x_mid, D, l.b_fc2}, st);
   }
-  APH_LAUNCH(head_fwd_kernel, dim3(S), dim3(256), sizeof(float) * D, st, (const float*)v->x_last, (const float*)v->ln_post_g,
-             (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
+  APH_LAUNCH(head_fwd_kernel, dim3(S, (v->E + 127) / 128), dim3(256), sizeof(float) * (D + 256), st, (const float*)v->x_last,
+             (const float*)v->ln_post_g, (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
   return aph_check_launch("aph_vit_forward");
   APH_CATCH
 }
@@ -269,7 +269,9 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
-  APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(256), sizeof(float) * (v->E + 2 * D), st, d_genc, (const float*)v->x_last,
+  (void)hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st);       // only the class rows carry gradient out of the head
+  (void)hipMemsetAsync(v->dx16, 0, sizeof(half_t) * (size_t)M * D, st);
+  APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];

@@ -233,70 +233,112 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(const half_t* __restr
     }
     gb_mma(acc, f1);                                        // k-step 1 of tile kt
   }
+  // Epilogue through LDS: every wave parks its 64x64 fp32 accumulator tile in its own slice of the (now idle)
+  // ring, then each lane picks up 8 CONSECUTIVE columns of one row -> 16/32-byte global accesses covering whole
+  // 128-byte lines, and 4x fewer store instructions than storing straight from the MFMA C/D layout.
+  __syncthreads();
+  constexpr int CT_LD = 68;                                   // floats per staged row (pad: conflict-free b128 writes)
+  float* ct = reinterpret_cast<float*>(smem) + wave * (64 * CT_LD);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
-    if (m < M) {
+  for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) epi(m, n0 + wn * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
-    }
+    for (int nt = 0; nt < 4; ++nt)
+      *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * CT_LD + nt * 16 + (lane >> 4) * 4) = acc[mt][nt];
+  wave_lds_fence();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * CT_LD + c8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * CT_LD + c8 + 4);
+    const int m = m0 + wm * 64 + r;
+    if (m < M) epi.apply8(m, n0 + wn * 64 + c8, a, b);
   }
 }
 
-// ---- epilogues (called with 4 consecutive columns n..n+3 of row m) ---------------------------
+// ---- epilogues: operator() gets 4 consecutive columns n..n+3 of row m, apply8 gets 8 -------------------
 __device__ __forceinline__ void store_h4(half_t* p, float a, float b, float c, float d) {
   half4 h = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
   *reinterpret_cast<half4*>(p) = h;
 }
+__device__ __forceinline__ void store_h8(half_t* p, const f32x4& a, const f32x4& b) {
+  half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  *reinterpret_cast<half8*>(p) = h;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 struct EpiF16 {          // out = acc (+ bias)
   half_t* out; int ldo; const float* bias;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-    if (bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n); v += b; }
+    if (bias) v += ld4(bias + n);
     store_h4(out + (size_t)m * ldo + n, v[0], v[1], v[2], v[3]);
+  }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    if (bias) { a += ld4(bias + n); b += ld4(bias + n + 4); }
+    store_h8(out + (size_t)m * ldo + n, a, b);
   }
 };
 
 struct EpiF32 {          // out = acc * scale  (fp32)
   float* out; int ldo; float scale;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-    *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + n) = v * scale;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { st4(out + (size_t)m * ldo + n, v * scale); }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    st4(out + (size_t)m * ldo + n, a * scale);
+    st4(out + (size_t)m * ldo + n + 4, b * scale);
   }
 };
 
 struct EpiResidual {     // out = res + acc + bias   (fp32 residual stream)
   float* out; const float* res; int ldo; const float* bias;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
-    const f32x4 r = *reinterpret_cast<const f32x4*>(res + (size_t)m * ldo + n);
-    *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + n) = r + v + b;
+    st4(out + (size_t)m * ldo + n, ld4(res + (size_t)m * ldo + n) + v + ld4(bias + n));
+  }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    (*this)(m, n, a);
+    (*this)(m, n + 4, b);
   }
 };
 
-struct EpiGelu {         // u = acc + bias (kept for the backward), g = u * sigmoid(1.702 u)   [QuickGELU]
-  half_t* u; half_t* g; int ldo; const float* bias;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-    v += *reinterpret_cast<const f32x4*>(bias + n);
-    store_h4(u + (size_t)m * ldo + n, v[0], v[1], v[2], v[3]);
-    float o[4];
+// QuickGELU g = u sigmoid(1.702 u) with u = acc + bias.  Besides g the forward stores the derivative
+// dg/du = s (1 + 1.702 u (1 - s)) (same sigmoid s, f16), so the backward's epilogue is one multiply.
+__device__ __forceinline__ void quick_gelu4(const f32x4& u, f32x4& g, f32x4& dg) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
-    store_h4(g + (size_t)m * ldo + n, o[0], o[1], o[2], o[3]);
+  for (int i = 0; i < 4; ++i) {
+    const float s = 1.0f / (1.0f + __expf(-1.702f * u[i]));
+    g[i] = u[i] * s;
+    dg[i] = s * (1.0f + 1.702f * u[i] * (1.0f - s));
+  }
+}
+struct EpiGelu {
+  half_t* dg; half_t* g; int ldo; const float* bias;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    v += ld4(bias + n);
+    f32x4 gg, dd;
+    quick_gelu4(v, gg, dd);
+    store_h4(g + (size_t)m * ldo + n, gg[0], gg[1], gg[2], gg[3]);
+    store_h4(dg + (size_t)m * ldo + n, dd[0], dd[1], dd[2], dd[3]);
+  }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    a += ld4(bias + n); b += ld4(bias + n + 4);
+    f32x4 ga, da, gb, db;
+    quick_gelu4(a, ga, da);
+    quick_gelu4(b, gb, db);
+    store_h8(g + (size_t)m * ldo + n, ga, gb);
+    store_h8(dg + (size_t)m * ldo + n, da, db);
   }
 };
 
-struct EpiGeluBwd {      // du = acc * d/du [u sigmoid(1.702 u)]
-  half_t* out; const half_t* u; int ldo;
+struct EpiGeluBwd {      // du = acc * dg/du (stored by the forward)
+  half_t* out; const half_t* dg; int ldo;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-    const half4 uh = *reinterpret_cast<const half4*>(u + (size_t)m * ldo + n);
-    float o[4];
+    const half4 d = *reinterpret_cast<const half4*>(dg + (size_t)m * ldo + n);
+    store_h4(out + (size_t)m * ldo + n, v[0] * (float)d[0], v[1] * (float)d[1], v[2] * (float)d[2], v[3] * (float)d[3]);
+  }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    const half8 d = *reinterpret_cast<const half8*>(dg + (size_t)m * ldo + n);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float x = (float)uh[i];
-      const float s = 1.0f / (1.0f + __expf(-1.702f * x));
-      o[i] = v[i] * (s * (1.0f + 1.702f * x * (1.0f - s)));
-    }
-    store_h4(out + (size_t)m * ldo + n, o[0], o[1], o[2], o[3]);
+    for (int i = 0; i < 4; ++i) { a[i] *= (float)d[i]; b[i] *= (float)d[4 + i]; }
+    store_h8(out + (size_t)m * ldo + n, a, b);
   }
 };
 
@@ -304,8 +346,11 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
   float* x0; const float* pos; int D, P, T;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
     const int s = m / P, p = m - s * P;
-    const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (size_t)(1 + p) * D + n);
-    *reinterpret_cast<f32x4*>(x0 + ((size_t)s * T + 1 + p) * D + n) = v + pe;
+    st4(x0 + ((size_t)s * T + 1 + p) * D + n, v + ld4(pos + (size_t)(1 + p) * D + n));
+  }
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    (*this)(m, n, a);
+    (*this)(m, n + 4, b);
   }
 };
 

@@ -287,12 +287,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// head: enc[s] = LN_post(x[s*T + 0]) @ proj        (proj [D, E] f32)
+// head: enc[s] = LN_post(x[s*T + 0]) @ proj        (proj [D, E] f32).  fp32 throughout.
+// grid (S, E/128), 256 threads: 128 outputs x 2 halves of the D reduction, 8 independent partial sums per
+// thread so the proj loads pipeline instead of serialising on L2 latency.
 // ---------------------------------------------------------------------------------
-__global__ void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ proj, float* __restrict__ enc, int T, int D, int E) {
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ proj,
+                                                      float* __restrict__ enc, int T, int D, int E) {
   APH_DYN_SMEM(smem);
-  float* y = reinterpret_cast<float*>(smem);
+  float* y = reinterpret_cast<float*>(smem);     // [D]
+  float* part = y + D;                           // [256]
   __shared__ float red[16];
   const int s = blockIdx.x;
   const float* row = x + (size_t)s * T * D;
@@ -304,48 +308,52 @@ __global__ void head_fwd_kernel(const float* __restrict__ x, const float* __rest
   const float rstd = rsqrtf(block_sum(q, red) / D + kLnEps);
   for (int d = threadIdx.x; d < D; d += blockDim.x) y[d] = (row[d] - mean) * rstd * gamma[d] + beta[d];
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc += y[d] * proj[(size_t)d * E + e];
-    enc[(size_t)s * E + e] = acc;
+  const int e = blockIdx.y * 128 + (threadIdx.x & 127), half = threadIdx.x >> 7;
+  const int dh = D >> 1, d0 = half * dh;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < E) {
+    int d = d0;
+    for (; d + 8 <= d0 + dh; d += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += y[d + u] * proj[(size_t)(d + u) * E + e];
+    }
+    for (; d < d0 + dh; ++d) acc[0] += y[d] * proj[(size_t)d * E + e];
   }
+  part[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (half == 0 && e < E) enc[(size_t)s * E + e] = part[threadIdx.x] + part[threadIdx.x + 128];
 }
 
-// head backward: genc [S,E] -> dx (fp32 [M,D], zero except class rows) and its f16 copy.
-// projT = proj transposed [E, D].
-__global__ void head_bwd_kernel(const float* __restrict__ genc, const float* __restrict__ x, const float* __restrict__ gamma,
-                                const float* __restrict__ projT, float* __restrict__ dx, half_t* __restrict__ dx16, int T, int D, int E) {
+// head backward: genc [S,E] -> the class-token rows of dx (fp32) and dx16; every other row of dx / dx16 must have
+// been zeroed by the caller (only the class token reaches the head).  projT = proj transposed [E, D].
+// One workgroup per image, one thread per feature d (blockDim.x == D <= 1024).
+__global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict__ genc, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ projT,
+                                                       float* __restrict__ dx, half_t* __restrict__ dx16, int T, int D, int E) {
   APH_DYN_SMEM(smem);
   float* ge = reinterpret_cast<float*>(smem);   // [E]
-  float* gy = ge + E;                            // [D]  gamma * dy
-  float* xh = gy + D;                            // [D]  xhat
   __shared__ float red[16];
-  const int s = blockIdx.x;
+  const int s = blockIdx.x, d = threadIdx.x;
   const float* row = x + (size_t)s * T * D;
   for (int e = threadIdx.x; e < E; e += blockDim.x) ge[e] = genc[(size_t)s * E + e];
-  float a = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) a += row[d];
-  const float mean = block_sum(a, red) / D;
-  float q = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) { const float c = row[d] - mean; q += c * c; }
-  const float rstd = rsqrtf(block_sum(q, red) / D + kLnEps);
-  float sg = 0.f, sgx = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float acc = 0.f;
-    for (int e = 0; e < E; ++e) acc += ge[e] * projT[(size_t)e * D + d];
-    const float g = acc * gamma[d], xv = (row[d] - mean) * rstd;
-    gy[d] = g; xh[d] = xv;
-    sg += g; sgx += g * xv;
+  const float xv = row[d];
+  const float mean = block_sum(xv, red) / D;                 // (block_sum's barriers also publish ge)
+  const float c = xv - mean;
+  const float rstd = rsqrtf(block_sum(c * c, red) / D + kLnEps);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int e = 0;
+  for (; e + 8 <= E; e += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += ge[e + u] * projT[(size_t)(e + u) * D + d];
   }
-  sg = block_sum(sg, red) / D;
-  sgx = block_sum(sgx, red) / D;
-  // class row gets the LN_post input-gradient, all other token rows of this image are zero
-  for (int idx = threadIdx.x; idx < T * D; idx += blockDim.x) {
-    const int t = idx / D, d = idx - t * D;
-    const float v = t == 0 ? rstd * (gy[d] - sg - xh[d] * sgx) : 0.f;
-    dx[(size_t)s * T * D + idx] = v;
-    dx16[(size_t)s * T * D + idx] = (half_t)v;
-  }
+  for (; e < E; ++e) acc[0] += ge[e] * projT[(size_t)e * D + d];
+  const float g = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) * gamma[d];
+  const float xh = c * rstd;
+  const float sg = block_sum(g, red) / D;
+  const float sgx = block_sum(g * xh, red) / D;
+  const float v = rstd * (g - sg - xh * sgx);
+  dx[(size_t)s * T * D + d] = v;
+  dx16[(size_t)s * T * D + d] = (half_t)v;
 }
 
 }  // namespace aph
