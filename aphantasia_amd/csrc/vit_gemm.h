@@ -227,11 +227,14 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(const half_t* __restr
     if (kt + 1 < nk) {
       wait_lgkm0();                                         // f1 has left LDS: stage st(kt) is dead for this wave
       if (kt + 2 < nk) wait_vm_barrier<6>(); else wait_vm_barrier<0>();
-      if (kt + 3 < nk) issue(kt + 3, st_cur == 0 ? GB_NSTAGE - 1 : st_cur - 1);   // refill the stage just released
+      // refill the stage just released.  The two waves that share a SIMD (w and w + 4) issue their DMA half a k-tile
+      // apart, so one of them always has MFMAs to issue while the other sits in the vector-memory issue queue.
+      if (wave < 4 && kt + 3 < nk) issue(kt + 3, st_cur == 0 ? GB_NSTAGE - 1 : st_cur - 1);
       const half_t* An = lds + st_cur * GB_STAGE;
       gb_load_frags(f0, An, An + GB_BM * GB_BK, arow, brow, fchunk);   // k-step 0 of tile kt+1: overlaps the MFMAs below
     }
     gb_mma(acc, f1);                                        // k-step 1 of tile kt
+    if (wave >= 4 && kt + 3 < nk) issue(kt + 3, st_cur == 0 ? GB_NSTAGE - 1 : st_cur - 1);
   }
   // Epilogue through LDS: every wave parks its 64x64 fp32 accumulator tile in its own slice of the (now idle)
   // ring, then each lane picks up 8 CONSECUTIVE columns of one row -> 16/32-byte global accesses covering whole
