@@ -21,7 +21,7 @@ from . import _ffi, ops
 from .clip import LOSS_SCALE
 from .image import colcorr_t, fft_scale
 from .transforms import Transform, pack_aug
-from .utils import draw_crop_params
+from .utils import draw_crop_params, draw_crop_params_bulk
 
 
 def shard_range(S, rank, world):
@@ -34,11 +34,14 @@ def shard_range(S, rank, world):
 class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
-                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None):
+                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
-        coef = sign*weight as at clip_fft.py:257-267."""
+        coef = sign*weight as at clip_fft.py:257-267.
+        rng: 'bulk' = vectorised host draws from a numpy Generator seeded off torch's global generator (same
+        distributions, ~0.1 ms/step); 'reference' = the reference's exact per-cut draw order on torch's / numpy's
+        global generators (a seeded run then reproduces the reference's crop tables; costs milliseconds of Python)."""
         self.params = params
         self.dev = params.device
         self.h, self.w = h, w
@@ -52,6 +55,9 @@ class Engine:
         self.lo, self.hi = shard_range(self.S, rank, world)
         self.S_loc = self.hi - self.lo
         self.sim = sim
+        self.rng_mode = rng
+        self.use_graph, self._graphs, self._calls = use_graph, None, 0
+        self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
         self.cc = colcorr_t(colors).flatten().tolist()
         self.decorrelate = decorrelate
@@ -123,6 +129,8 @@ class Engine:
     # ------------------------------------------------------------------
     def draw(self):
         """Host-side random draws for one step (the reference's own order, utils.py:222-251)."""
+        if self.rng_mode == 'bulk':
+            return draw_crop_params_bulk(self.S, self.size, self.h, self.w, self.align, self.macro, self.transform, self.np_rng)
         return draw_crop_params(self.S, self.size, self.h, self.w, self.align, self.macro, self.transform)
 
     def synthesize(self, contrast=1.0, shift=None):
@@ -137,21 +145,10 @@ class Engine:
                    int(self.decorrelate), ops.ptr(self.rgb), st)
         return self.rgb
 
-    def step(self, table=None, augs=None, lr=None, shift=None):
-        """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
-        if table is None:
-            table, augs = self.draw()
+    def _enqueue_grad(self, shift):
+        """forward + backward up to the parameter gradient: C-ABI calls only (capturable into a hipGraph)"""
         L, st = self.lib, ops._stream(self.params)
         Sl = self.S_loc
-        self._state['step'][0] += 1
-        lr = self.lr if lr is None else lr
-        hy = ops.adam_hyper(self._state['step'][0], lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
-        self.hyper.copy_(torch.tensor(hy, dtype=torch.float32), non_blocking=True)
-        if Sl > 0:
-            self.table.copy_(torch.from_numpy(np.ascontiguousarray(table[self.lo:self.hi])), non_blocking=True)
-            if self.geometric:
-                self.aug.copy_(pack_aug(augs[self.lo:self.hi]), non_blocking=True)
-        # forward
         self.synthesize(1.0, shift)
         cc = _ffi.floats(self.cc)
         if Sl > 0:
@@ -161,7 +158,6 @@ class Engine:
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
                    len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
-            # backward
             self.visual.handle.backward(self.genc, Sl, self.gpatch, 1.0 / LOSS_SCALE)
             L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), 1.0, ops.ptr(self.table), ops.ptr(self.aug),
                    ops.ptr(self.tmp), ops.ptr(self.grgb), _ffi.APH_OUT_PATCH_F16, st)
@@ -178,11 +174,59 @@ class Engine:
         else:
             L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, 0.0, cc,
                    int(self.decorrelate), ops.ptr(self.grad), st)
+
+    def _enqueue_adam(self):
+        self.lib.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
+                      ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), ops._stream(self.params))
+
+    def _capture(self):
+        """Record the step's ~280 launches into hipGraphs (replayed per step: the host then costs three tiny H2D copies
+        and one or two graph launches).  Everything the kernels read that changes per step -- crop table, augment table,
+        Adam scalars -- lives in fixed device buffers refreshed before the replay."""
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._enqueue_grad(None)
+            if self.world == 1:
+                self._enqueue_adam()
+        g2 = None
+        if self.world > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self._enqueue_adam()
+        self._graphs = (g1, g2)
+
+    def step(self, table=None, augs=None, lr=None, shift=None):
+        """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
+        if table is None:
+            table, augs = self.draw()
+        Sl = self.S_loc
+        self._state['step'][0] += 1
+        self._calls += 1
+        lr = self.lr if lr is None else lr
+        hy = ops.adam_hyper(self._state['step'][0], lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
+        self.hyper.copy_(torch.tensor(hy, dtype=torch.float32), non_blocking=True)
+        if Sl > 0:
+            self.table.copy_(torch.from_numpy(np.ascontiguousarray(table[self.lo:self.hi])), non_blocking=True)
+            if self.geometric:
+                packed = torch.from_numpy(np.ascontiguousarray(augs[self.lo:self.hi])) if isinstance(augs, np.ndarray) else pack_aug(augs[self.lo:self.hi])
+                self.aug.copy_(packed, non_blocking=True)
+        use_graph = self.use_graph and shift is None and self.params.is_cuda
+        if use_graph and self._graphs is None and self._calls > 2:      # two eager steps first (one-time kernel attributes, allocator warm-up)
+            self._capture()
+        if use_graph and self._graphs is not None:
+            self._graphs[0].replay()
+            self.visual._generation += 1
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
+                self._graphs[1].replay()
+            return self.loss
+        self._enqueue_grad(shift)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
-        L.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
-               ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), st)
+        self._enqueue_adam()
         return self.loss
 
     def global_loss(self):

@@ -37,12 +37,12 @@ class _Fast(Transform):
 
     def draw(self, size):
         prm = dict(persp=None, erase=None, angle=0.0)
-        if torch.rand(1) < 0.2:
+        if _RU.uniform_().item() < 0.2:              # `torch.rand(1) < p` (fp32 compare; 0.2f > 0.2 and no fp32 lies between)
             sp, ep = _perspective_params(size, size, 0.33)
             prm['persp'] = _perspective_coeffs(sp, ep)
-        if torch.rand(1) < 0.2:
+        if _RU.uniform_().item() < 0.2:
             prm['erase'] = _erase_params(size, size)
-        prm['angle'] = float(np.random.choice(ROT_ANGLES_FAST))   # transforms.py:75
+        prm['angle'] = float(ROT_ANGLES_FAST[np.random.randint(0, len(ROT_ANGLES_FAST))])   # == np.random.choice (same stream), transforms.py:75
         return prm
 
 
@@ -54,12 +54,16 @@ def normalize():
 transforms_fast = _Fast()
 
 
+_RI = torch.empty(1, dtype=torch.int64)
+_RU = torch.empty(1)
+
+
 def _perspective_params(width, height, distortion_scale):
     hh, hw = height // 2, width // 2
     dw, dh = int(distortion_scale * hw), int(distortion_scale * hh)
 
-    def ri(lo, hi):
-        return int(torch.randint(lo, hi, size=(1,)).item())
+    def ri(lo, hi):                       # == torch.randint(lo, hi, (1,)) on the global generator, without the allocation
+        return int(_RI.random_(lo, hi).item())
     tl = [ri(0, dw + 1), ri(0, dh + 1)]
     tr = [ri(width - dw - 1, width), ri(0, dh + 1)]
     br = [ri(width - dw - 1, width), ri(height - dh - 1, height)]
@@ -74,22 +78,23 @@ def _perspective_coeffs(startpoints, endpoints):
         a[2 * i] = [p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]]
         a[2 * i + 1] = [0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]]
     b = np.asarray(startpoints, dtype=np.float64).reshape(8)
-    res = torch.linalg.lstsq(torch.from_numpy(a), torch.from_numpy(b), driver='gels').solution.to(torch.float32)
-    return res.tolist()
+    # torchvision solves this square full-rank system with lstsq(gels) in fp64 and casts to fp32; a direct fp64 solve
+    # agrees to ~1e-14 before the cast
+    return np.linalg.solve(a, b).astype(np.float32).tolist()
 
 
 def _erase_params(img_h, img_w, scale=(0.02, 0.33), ratio=(0.3, 3.3)):
     area = img_h * img_w
     log_ratio = torch.log(torch.tensor(ratio))
     for _ in range(10):
-        erase_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
-        aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        erase_area = area * _RU.uniform_(scale[0], scale[1]).item()
+        aspect = torch.exp(_RU.uniform_(log_ratio[0], log_ratio[1])).item()
         h = int(round(math.sqrt(erase_area * aspect)))
         w = int(round(math.sqrt(erase_area / aspect)))
         if not (h < img_h and w < img_w):
             continue
-        i = int(torch.randint(0, img_h - h + 1, size=(1,)).item())
-        j = int(torch.randint(0, img_w - w + 1, size=(1,)).item())
+        i = int(_RI.random_(0, img_h - h + 1).item())
+        j = int(_RI.random_(0, img_w - w + 1).item())
         return i, j, h, w
     return None
 
@@ -107,4 +112,53 @@ def pack_aug(prms):
         if ang is not None:
             rot = math.radians(float(ang))
             t[s, 13], t[s, 14], t[s, 15] = math.cos(rot), math.sin(rot), 1.0
+    return t
+
+
+# ----------------------------------------------------------------------------- bulk (vectorised) draws
+def draw_fast_bulk(S, size, rng):
+    """transforms_fast parameters for S cuts at once from a numpy Generator -> packed f32 [S,16] table.
+    Same distributions as the per-cut draws above (torchvision get_params), NOT the reference's random stream."""
+    t = np.zeros((S, _ffi.APH_AUG_STRIDE), dtype=np.float32)
+    hw = size // 2
+    dw = int(0.33 * hw)
+    # RandomPerspective(0.33, p=0.2)
+    idx = np.nonzero(rng.random(S) < 0.2)[0]
+    if idx.size:
+        n = idx.size
+        lo = rng.integers(0, dw + 1, size=(n, 4))                     # near-edge offsets
+        hi = rng.integers(size - dw - 1, size, size=(n, 4))           # far-edge coordinates
+        end = np.stack([np.stack([lo[:, 0], lo[:, 1]], 1), np.stack([hi[:, 0], lo[:, 2]], 1),
+                        np.stack([hi[:, 1], hi[:, 2]], 1), np.stack([lo[:, 3], hi[:, 3]], 1)], 1).astype(np.float64)   # tl,tr,br,bl
+        start = np.array([[0, 0], [size - 1, 0], [size - 1, size - 1], [0, size - 1]], dtype=np.float64)
+        a = np.zeros((n, 8, 8))
+        for i in range(4):
+            p1, p2 = end[:, i], start[i]
+            a[:, 2 * i, 0], a[:, 2 * i, 1], a[:, 2 * i, 2] = p1[:, 0], p1[:, 1], 1
+            a[:, 2 * i, 6], a[:, 2 * i, 7] = -p2[0] * p1[:, 0], -p2[0] * p1[:, 1]
+            a[:, 2 * i + 1, 3], a[:, 2 * i + 1, 4], a[:, 2 * i + 1, 5] = p1[:, 0], p1[:, 1], 1
+            a[:, 2 * i + 1, 6], a[:, 2 * i + 1, 7] = -p2[1] * p1[:, 0], -p2[1] * p1[:, 1]
+        b = np.broadcast_to(start.reshape(8), (n, 8))
+        t[idx, 0:8] = np.linalg.solve(a, b[..., None])[..., 0].astype(np.float32)
+        t[idx, 8] = 1.0
+    # RandomErasing(p=0.2): up to 10 tries of (area in [.02,.33], log-uniform aspect in [.3,3.3])
+    idx = np.nonzero(rng.random(S) < 0.2)[0]
+    if idx.size:
+        n = idx.size
+        area = size * size * rng.uniform(0.02, 0.33, size=(n, 10))
+        asp = np.exp(rng.uniform(math.log(0.3), math.log(3.3), size=(n, 10)))
+        eh = np.rint(np.sqrt(area * asp)).astype(np.int64)
+        ew = np.rint(np.sqrt(area / asp)).astype(np.int64)
+        ok = (eh < size) & (ew < size)
+        first = np.argmax(ok, axis=1)
+        any_ok = ok.any(axis=1)
+        eh, ew = eh[np.arange(n), first], ew[np.arange(n), first]
+        ei = np.floor(rng.random(n) * (size - eh + 1)).astype(np.int64)
+        ej = np.floor(rng.random(n) * (size - ew + 1)).astype(np.int64)
+        sel = idx[any_ok]
+        t[sel, 9], t[sel, 10], t[sel, 11], t[sel, 12] = ei[any_ok], ej[any_ok], eh[any_ok], ew[any_ok]
+    # random_rotate_fast
+    ang = np.asarray(ROT_ANGLES_FAST, dtype=np.float64)[rng.integers(0, len(ROT_ANGLES_FAST), size=S)]
+    rot = np.radians(ang)
+    t[:, 13], t[:, 14], t[:, 15] = np.cos(rot), np.sin(rot), 1.0
     return t

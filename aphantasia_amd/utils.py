@@ -49,6 +49,37 @@ def draw_crop_params(count, size, h, w, align='uniform', macro=0., transform=Non
     return table, augs
 
 
+def draw_crop_params_bulk(count, size, h, w, align, macro, transform, rng):
+    """Vectorised draws with the same distributions and fp32/truncation arithmetic as draw_crop_params but from a
+    numpy Generator (NOT the reference's random stream): for throughput, ~0.1 ms instead of ms per step.
+    -> (int32 [count,3], packed f32 [count,16] augment table or None)"""
+    f32 = np.float32
+    r_size = rng.random(count, dtype=f32)
+    if align == 'central':
+        r_x = np.clip(rng.standard_normal(count, dtype=f32) * f32(0.2) + f32(0.5), 0., 1.).astype(f32)
+        r_y = np.clip(rng.standard_normal(count, dtype=f32) * f32(0.2) + f32(0.5), 0., 1.).astype(f32)
+    else:
+        r_x, r_y = rng.random(count, dtype=f32), rng.random(count, dtype=f32)
+    sz_max = min(h, w)
+    ph, pw = h, w
+    if 'over' in align:
+        ph, pw = (2 * h, 2 * w) if align == 'overmax' else (int(1.5 * h), int(1.5 * w))
+    big_min = f32(0.9) * f32(sz_max)
+    is_macro = rng.random(count, dtype=f32) < f32(macro)
+    cs_macro = (r_size * (f32(sz_max) - big_min) + big_min).astype(np.int32)
+    cs_plain = (r_size * f32(sz_max - size) + f32(size)).astype(np.int32)
+    csize = np.where(is_macro, cs_macro, cs_plain).astype(np.int32)
+    table = np.empty((count, 3), dtype=np.int32)
+    table[:, 0] = csize
+    table[:, 1] = (r_x * (pw - csize).astype(f32)).astype(np.int32)
+    table[:, 2] = (r_y * (ph - csize).astype(f32)).astype(np.int32)
+    aug = None
+    if isinstance(transform, Transform) and transform.geometric:
+        from .transforms import draw_fast_bulk
+        aug = draw_fast_bulk(count, size, rng)
+    return table, aug
+
+
 class _Slice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, geom, table, aug, out_mode):

@@ -126,6 +126,7 @@ def main():
         # same steps again with HIP events around every GEMM launch of the ViT (dominant kernel family)
         lib = eng.lib
         h_ = eng.visual.handle
+        eng.use_graph = False             # eager launches so that every GEMM gets its event pair
         lib.call('aph_vit_profile', h_.handle, 1)
         for _ in range(min(a.steps, 10)):
             eng.step()

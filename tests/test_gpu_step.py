@@ -185,9 +185,9 @@ def test_dwt_and_pixel_engines_vs_autograd_api(model):
         grads = torch.cat([p.grad.reshape(-1) for p in params])
         if kind == 'dwt':
             eng = Engine(image_f.flat.detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(),
-                         param_kind='dwt', dwt=image_f.synth)
+                         param_kind='dwt', dwt=image_f.synth, rng='reference')
         else:
-            eng = Engine(params[0].detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(), param_kind='pixel')
+            eng = Engine(params[0].detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(), param_kind='pixel', rng='reference')
         seed_all(5)
         l2 = float(eng.step())
         assert abs(l2 - float(loss)) < 1e-5, kind
