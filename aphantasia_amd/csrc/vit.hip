@@ -322,7 +322,7 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
 // plain C = A * Bt^T (f16 in, f32 out) -- exported for the GEMM unit tests and micro-benchmarks
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream_) {
   APH_TRY
-  if (!d_A || !d_Bt || !d_C || M < 1 || N % GEMM_BN || K % GEMM_BK || N < 1 || K < 1)
+  if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1)
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
   launch_gemm((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
   return aph_check_launch("aph_gemm_f16");
@@ -332,7 +332,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 // same with explicit leading dimensions (row pitches in elements) -- layout experiments
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, void* stream_) {
   APH_TRY
-  if (!d_A || !d_Bt || !d_C || M < 1 || N % GEMM_BN || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7))
+  if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   launch_gemm((const half_t*)d_A, lda, (const half_t*)d_Bt, ldb, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
   return aph_check_launch("aph_gemm_f16_ld");
