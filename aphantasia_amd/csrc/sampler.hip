@@ -65,6 +65,35 @@ __device__ __forceinline__ float fetch_grad(const float* __restrict__ gout, int 
   return gout[patch_index(s, c, i, j, size, patch)] / kClipStd[c];
 }
 
+// all three channels of cut pixel (i, j): one index computation (the patch-major index needs integer divisions)
+template <int OUT>
+__device__ __forceinline__ void fetch_grad3(const float* __restrict__ gout, int s, int i, int j, int size, int patch, float g[3]) {
+  if (OUT == APH_OUT_PATCH_F16) {
+    const size_t o = patch_index(s, 0, i, j, size, patch);
+    const int pp = patch * patch;
+    g[0] = gout[o] / kClipStd[0]; g[1] = gout[o + pp] / kClipStd[1]; g[2] = gout[o + 2 * pp] / kClipStd[2];
+  } else {
+    const size_t o = ((size_t)s * 3 * size + i) * size + j, nn = (size_t)size * size;
+    g[0] = gout[o]; g[1] = gout[o + nn]; g[2] = gout[o + 2 * nn];
+    if (OUT == APH_OUT_NCHW_NORM) { g[0] /= kClipStd[0]; g[1] /= kClipStd[1]; g[2] /= kClipStd[2]; }
+  }
+}
+template <int OUT>
+__device__ __forceinline__ void emit3(void* out, int s, int i, int j, int size, int patch, float v0, float v1, float v2) {
+  if (OUT == APH_OUT_PATCH_F16) {
+    const size_t o = patch_index(s, 0, i, j, size, patch);
+    const int pp = patch * patch;
+    half_t* q = reinterpret_cast<half_t*>(out);
+    q[o] = (half_t)((v0 - kClipMean[0]) / kClipStd[0]);
+    q[o + pp] = (half_t)((v1 - kClipMean[1]) / kClipStd[1]);
+    q[o + 2 * pp] = (half_t)((v2 - kClipMean[2]) / kClipStd[2]);
+  } else {
+    emit<OUT>(out, s, 0, i, j, size, patch, v0);
+    emit<OUT>(out, s, 1, i, j, size, patch, v1);
+    emit<OUT>(out, s, 2, i, j, size, patch, v2);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // crop + bicubic resize  (utils.py:248-249)
 // ---------------------------------------------------------------------------------
@@ -90,6 +119,7 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __r
     ry[k] = wrap(oy + yy - g.py0, g.H);                                     // tile_pad wrap (utils.py:165-167)
     rx[k] = wrap(ox + xx - g.px0, g.W);
   }
+  float v[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* pl = rgb + (size_t)c * g.H * g.W;
@@ -100,8 +130,9 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __r
       const float r = row[rx[0]] * wx[0] + row[rx[1]] * wx[1] + row[rx[2]] * wx[2] + row[rx[3]] * wx[3];
       acc += r * wy[a];
     }
-    emit<OUT>(out, s, c, i, j, g.size, g.patch, acc);
+    v[c] = acc;
   }
+  emit3<OUT>(out, s, i, j, g.size, g.patch, v[0], v[1], v[2]);
 }
 
 // Adjoint of crop_resize over all cuts -- deterministic gather, one 16x16 pixel tile per workgroup.
@@ -375,13 +406,13 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
   const float* src = a[8] != 0.f ? Bi : A;
   if (a[15] != 0.f) {
     const Tap t = rot_tap(a[13], a[14], i, j, n);
-    for (int c = 0; c < 3; ++c)
-      emit<OUT>(out, s, c, i, j, n, patch, warp_gather<true>(src + ((size_t)s * 3 + c) * n * n, t, n, a));
+    float v[3];
+    for (int c = 0; c < 3; ++c) v[c] = warp_gather<true>(src + ((size_t)s * 3 + c) * n * n, t, n, a);
+    emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
   } else {
-    for (int c = 0; c < 3; ++c) {
-      const float v = in_rect(a, i, j) ? 0.f : src[((size_t)s * 3 + c) * n * n + pix];
-      emit<OUT>(out, s, c, i, j, n, patch, v);
-    }
+    float v[3];
+    for (int c = 0; c < 3; ++c) v[c] = in_rect(a, i, j) ? 0.f : src[((size_t)s * 3 + c) * n * n + pix];
+    emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
   }
 }
 
@@ -427,14 +458,14 @@ __global__ void rotate_emit_adjoint_kernel(const float* __restrict__ gout, const
           const float w = tap_hits(t, py, px);
           if (w == 0.f) continue;
           const float wm = w * tap_mask(t, n);
-          g0 += wm * fetch_grad<OUT>(gout, s, 0, i, j, n, patch);
-          g1 += wm * fetch_grad<OUT>(gout, s, 1, i, j, n, patch);
-          g2 += wm * fetch_grad<OUT>(gout, s, 2, i, j, n, patch);
+          float gq[3];
+          fetch_grad3<OUT>(gout, s, i, j, n, patch, gq);
+          g0 += wm * gq[0]; g1 += wm * gq[1]; g2 += wm * gq[2];
         }
     } else {
-      g0 = fetch_grad<OUT>(gout, s, 0, py, px, n, patch);
-      g1 = fetch_grad<OUT>(gout, s, 1, py, px, n, patch);
-      g2 = fetch_grad<OUT>(gout, s, 2, py, px, n, patch);
+      float gq[3];
+      fetch_grad3<OUT>(gout, s, py, px, n, patch, gq);
+      g0 = gq[0]; g1 = gq[1]; g2 = gq[2];
     }
   }
   const size_t pl = (size_t)s * 3 * n * n;

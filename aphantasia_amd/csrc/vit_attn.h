@@ -22,22 +22,33 @@ __device__ __forceinline__ int slot_of(int n) { return ((n >> 5) << 5) + (((n >>
 // [64 rows][64 halfs] tile, 16-byte chunks XOR-swizzled exactly like the GEMM tiles (conflict-free b128 reads)
 __device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__device__ __forceinline__ void at_zero(half_t* lds, int halfs) {
-  const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int q = threadIdx.x; q < halfs / 8; q += blockDim.x) *reinterpret_cast<half8*>(lds + q * 8) = z;
-}
-
-// stage T rows x 64 halfs from global (row stride ld) into a swizzled row-major tile and/or its
-// transposed slot-permuted image
-__device__ __forceinline__ void at_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed) {
-  for (int q = threadIdx.x; q < T * 8; q += blockDim.x) {
-    const int r = q >> 3, c = q & 7;
-    const half8 v = *reinterpret_cast<const half8*>(src + (size_t)r * ld + c * 8);
-    if (rowmajor) *reinterpret_cast<half8*>(rowmajor + at_off(r, c)) = v;
-    if (transposed) {
-      const int s = slot_of(r), sc = s >> 3, sw = s & 7;
+// Stage one 64x64 tile (T valid rows of 64 halfs, row stride ld in global) into LDS as a swizzled row-major image
+// and/or as its transposed slot-permuted image.  64 work items cover the tile: item = (d-chunk c, slot-chunk sc),
+// sc fastest.  An item loads the 8 rows whose slots form chunk sc (16 bytes each, rows >= T read as zero),
+// transposes the 8x8 block in registers and writes 8 + 8 full 16-byte chunks -- no scattered 2-byte LDS stores, no
+// separate zero fill, and the 8 lanes of a store group hit 8 different 16-byte slots of one 128-byte row.
+__device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, int ld, int T, int item, half_t* rowmajor,
+                                              half_t* transposed) {
+  const int c = item >> 3, sc = item & 7;
+  const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);          // rows n(sc, i) = nbase + (i >> 2) * 16 + (i & 3)
+  half8 rows[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) transposed[at_off(c * 8 + e, sc) + sw] = v[e];
+  for (int i = 0; i < 8; ++i) {
+    const int n = nbase + ((i >> 2) << 4) + (i & 3);
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    rows[i] = n < T ? *reinterpret_cast<const half8*>(src + (size_t)n * ld + c * 8) : z;
+  }
+  if (rowmajor) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<half8*>(rowmajor + at_off(nbase + ((i >> 2) << 4) + (i & 3), c)) = rows[i];
+  }
+  if (transposed) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      half8 col;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) col[i] = rows[i][e];
+      *reinterpret_cast<half8*>(transposed + at_off(c * 8 + e, sc)) = col;
     }
   }
 }
@@ -61,11 +72,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
   const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
   const int D = heads * 64, ld = 3 * D;
   const half_t* base = qkv + (size_t)s * T * ld + h * 64;
-  at_zero(lds, 3 * 64 * 64);
-  __syncthreads();
-  at_stage(base, ld, T, Qs, nullptr);
-  at_stage(base + D, ld, T, Ks, nullptr);
-  at_stage(base + 2 * D, ld, T, nullptr, Vt);
+  {
+    const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
+    if (which == 0) at_stage_item(base, ld, T, item, Qs, nullptr);
+    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, nullptr);
+    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, nullptr, Vt);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, it = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
   if (it * 16 >= T) return;
@@ -133,12 +145,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
   const half_t* base = qkv + (size_t)s * T * ld + h * 64;
   const half_t* dob = datt + (size_t)s * T * D + h * 64;
   const half_t* ob = att + (size_t)s * T * D + h * 64;
-  at_zero(lds, 7 * 4096);
-  __syncthreads();
-  at_stage(base, ld, T, Qs, Qt);
-  at_stage(base + D, ld, T, Ks, Kt);
-  at_stage(base + 2 * D, ld, T, Vs, nullptr);
-  at_stage(dob, D, T, Os, Ot);
+  {
+    const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
+    if (which == 0) at_stage_item(base, ld, T, item, Qs, Qt);
+    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, Kt);
+    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, Vs, nullptr);
+    else at_stage_item(dob, D, T, item, Os, Ot);
+  }
   {
     // D_i = dO_i . O_i : 4 threads per row
     const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
