@@ -329,12 +329,21 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
   APH_CATCH
 }
 
-// same with explicit leading dimensions (row pitches in elements) -- layout experiments
-int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, void* stream_) {
+// same with explicit leading dimensions (row pitches in elements) and tile configuration
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256 [needs N % 256 == 0]) -- unit tests and layout experiments
+int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
-  if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7))
+  if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
+      tile_cfg < 0 || tile_cfg > 3 || (tile_cfg == 3 && N % 256))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
-  launch_gemm((const half_t*)d_A, lda, (const half_t*)d_Bt, ldb, M, N, K, EpiF32{d_C, N, 1.0f}, (hipStream_t)stream_);
+  const half_t* A = (const half_t*)d_A;
+  const half_t* B = (const half_t*)d_Bt;
+  const EpiF32 epi{d_C, N, 1.0f};
+  hipStream_t st = (hipStream_t)stream_;
+  if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 3) launch_gemm_cfg<GemmHuge>(A, lda, B, ldb, M, N, K, epi, st);
+  else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH
 }

@@ -4,7 +4,9 @@
 //
 // Both operands are K-contiguous, so the forward (activations x weight^T) and the dgrad (d_out x weight, using a
 // pre-transposed weight copy) run through the same kernel.  One kernel template, two tile configurations:
-//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS  -- the full-batch shapes (M ~ 9500);
+//   * 256x256x64, 8 waves (2x4 of 128x64), 2-stage ring, 128 KiB LDS -- wide outputs (N >= 2304) at full batch: a CU can
+//     pull ~110 GB/s through the LDS-DMA path (measured), which a 256x128 tile needs ALL of at full MFMA rate;
+//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS  -- the full-batch shapes (M ~ 9500), N = 768;
 //   *  64x 64x64, 4 waves (2x2 of 32x32), 4-stage ring,  64 KiB LDS (2 workgroups per CU) -- whenever the large
 //     tile would leave CUs idle (per-rank shards of a multi-GPU run, small batches).
 // Structure (cdna_hip_programming.md section 5):
@@ -29,9 +31,10 @@ constexpr int GEMM_BK = 64;
 // LDS tile: [rows][8 chunks of 8 halfs]; chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7)
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
+template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_, bool PIPE_ = true>
 struct GemmCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_;
+  static constexpr bool PIPE = PIPE_;          // fragment reads software-pipelined one k-step ahead (costs a 2nd fragment set)
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   static constexpr int NWAVE = WM * WN, NTHREAD = NWAVE * 64;
   static constexpr int STAGE = (BM + BN) * GEMM_BK;                 // halfs per stage
@@ -39,11 +42,14 @@ struct GemmCfg {
   static constexpr int GPT = GA + GB;
   static constexpr int CT_LD = TN * 16 + 4;                         // staged accumulator row pitch (floats)
   static constexpr int SMEM = NSTAGE * STAGE * 2;                   // bytes
+  // accumulator rows (in 16-row MFMA tiles) a wave stages per epilogue pass: all of them if the ring is big enough
+  static constexpr int EP_MT = (NWAVE * TM * 16 * CT_LD * 4 <= SMEM) ? TM : 2;
   static_assert(BM % (8 * NWAVE) == 0 && BN % (8 * NWAVE) == 0, "DMA row groups must divide over the waves");
-  static_assert(NWAVE * TM * 16 * CT_LD * 4 <= SMEM, "epilogue staging must fit in the ring");
-  static_assert(NSTAGE >= 3 && NSTAGE <= 4, "ring depth");
+  static_assert(NWAVE * EP_MT * 16 * CT_LD * 4 <= SMEM && TM % EP_MT == 0, "epilogue staging must fit in the ring");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
 };
-using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB
+using GemmHuge = GemmCfg<2, 4, 8, 4, 2, false>;   // 256 x 256, 512 threads, 128 KiB: 128 flop per L2 byte (128 acc VGPRs: one fragment set)
+using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
 
 template <class C>
@@ -135,45 +141,60 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     if (t < nk) issue(t, t);
   ring_wait<C>((nk - 1 < C::NSTAGE - 2) ? nk - 1 : C::NSTAGE - 2);
   if (C::NSTAGE - 1 < nk) issue(C::NSTAGE - 1, C::NSTAGE - 1);
-  gemm_load_frags<C>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
+  if (C::PIPE) gemm_load_frags<C>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
   int st_cur = 0;
   const bool late = wave >= C::NWAVE / 2;      // the SIMD partner of wave w - NWAVE/2: issues its DMA half a k-tile later
   for (int kt = 0; kt < nk; ++kt) {
     const half_t* As = lds + st_cur * C::STAGE;
-    gemm_load_frags<C>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);   // k-step 1 of tile kt: in flight during the MFMAs
-    gemm_mma<C>(acc, f0);                                                      // k-step 0 of tile kt
     const int st_free = st_cur;
     st_cur = st_cur == C::NSTAGE - 1 ? 0 : st_cur + 1;
-    if (kt + 1 < nk) {
-      wait_lgkm0();                                                            // f1 has left LDS: stage st_free is dead for this wave
-      const int rem = nk - 2 - kt;
-      ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);
-      if (!late && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
-      const half_t* An = lds + st_cur * C::STAGE;
-      gemm_load_frags<C>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);     // k-step 0 of tile kt+1: overlaps the MFMAs below
+    const int rem = nk - 2 - kt;
+    if (C::PIPE) {
+      gemm_load_frags<C>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);   // k-step 1 of tile kt: in flight during the MFMAs
+      gemm_mma<C>(acc, f0);                                                      // k-step 0 of tile kt
+      if (kt + 1 < nk) {
+        wait_lgkm0();                                                            // f1 has left LDS: stage st_free is dead for this wave
+        ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);
+        if (!late && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
+        const half_t* An = lds + st_cur * C::STAGE;
+        gemm_load_frags<C>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);     // k-step 0 of tile kt+1: overlaps the MFMAs below
+      }
+      gemm_mma<C>(acc, f1);                                                      // k-step 1 of tile kt
+      if (late && kt + 1 < nk && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
+    } else {
+      gemm_load_frags<C>(f0, As, As + C::BM * GEMM_BK, arow, brow, fchunk);
+      gemm_mma<C>(acc, f0);
+      gemm_load_frags<C>(f0, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
+      gemm_mma<C>(acc, f0);
+      if (kt + 1 < nk) {
+        ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);                 // (the MFMAs above consumed every fragment read)
+        if (kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
+      }
     }
-    gemm_mma<C>(acc, f1);                                                      // k-step 1 of tile kt
-    if (late && kt + 1 < nk && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
   }
   // Epilogue through LDS: every wave parks its fp32 accumulator tile in its own slice of the (now idle) ring, then each
   // lane picks up 8 CONSECUTIVE columns of one row.
   __syncthreads();
-  float* ct = reinterpret_cast<float*>(smem) + wave * (C::TM * 16 * C::CT_LD);
-#pragma unroll
-  for (int mt = 0; mt < C::TM; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < C::TN; ++nt)
-      *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[mt][nt];
-  wave_lds_fence();
+  float* ct = reinterpret_cast<float*>(smem) + wave * (C::EP_MT * 16 * C::CT_LD);
   constexpr int CPR = C::TN * 2;                 // 8-column chunks per row
   constexpr int RPI = 64 / CPR;                  // rows covered by one pass of the wave
 #pragma unroll
-  for (int it = 0; it < C::TM * 16 / RPI; ++it) {
-    const int r = it * RPI + lane / CPR, c8 = (lane % CPR) * 8;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
-    const int m = m0 + wm * C::TM * 16 + r;
-    if (m < M) epi.apply8(m, n0 + wn * C::TN * 16 + c8, a, b);
+  for (int p0 = 0; p0 < C::TM; p0 += C::EP_MT) {
+    wave_lds_fence();
+#pragma unroll
+    for (int mt = 0; mt < C::EP_MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::TN; ++nt)
+        *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < C::EP_MT * 16 / RPI; ++it) {
+      const int r = it * RPI + lane / CPR, c8 = (lane % CPR) * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
+      const int m = m0 + (wm * C::TM + p0) * 16 + r;
+      if (m < M) epi.apply8(m, n0 + wn * C::TN * 16 + c8, a, b);
+    }
   }
 }
 
@@ -270,7 +291,9 @@ inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb,
 template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
-  if (big_tiles >= 96) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
+  const int huge_tiles = (N / GemmHuge::BN) * ((M + GemmHuge::BM - 1) / GemmHuge::BM);
+  if (N % GemmHuge::BN == 0 && huge_tiles >= 400) launch_gemm_cfg<GemmHuge>(A, lda, Bt, ldb, M, N, K, epi, st);
+  else if (big_tiles >= 96) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
 }
 

@@ -199,12 +199,13 @@ class VitHandle:
             pass
 
 
-def gemm_f16(A, Bt, lib=None):
+def gemm_f16(A, Bt, lib=None, tile_cfg=0):
+    """C = A @ Bt^T (f16 in, f32 out); tile_cfg: 0 auto, 1 = 64x64, 2 = 256x128, 3 = 256x256 tiles"""
     L = _L(lib, A, Bt)
     M, K = A.shape
     N = Bt.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    L.call('aph_gemm_f16', ptr(A), ptr(Bt), M, N, K, ptr(C), _stream(A))
+    L.call('aph_gemm_f16_ld', ptr(A), K, ptr(Bt), K, M, N, K, ptr(C), int(tile_cfg), _stream(A))
     return C
 
 

@@ -123,7 +123,9 @@ int aph_vit_profile(aph_vit* vit, int on);
 int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
 /* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core, exported for tests */
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
-int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, void* stream);
+/* same with explicit row pitches and tile configuration (0 auto, 1 = 64x64, 2 = 256x128, 3 = 256x256): unit tests */
+int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
+                    void* stream);
 
 /* ---- loss: aphantasia/utils.py:270-295 sim_func, assembled as at clip_fft.py:257-267 -------- */
 #define APH_SIM_COS 0   /* type None / 'cossim' */

@@ -209,12 +209,12 @@ def check_adam(lib, dev, n=5000):
             assert (p.cpu() - q.detach()).abs().max().item() < 2e-6, name
 
 
-def check_gemm(lib, dev, shapes):
+def check_gemm(lib, dev, shapes, tile_cfg=0):
     gen = torch.Generator().manual_seed(0)
     for (M, Nn, K) in shapes:
         A = torch.randn(M, K, generator=gen).half()
         Bt = torch.randn(Nn, K, generator=gen).half()       # asymmetric operands (catches transposes)
-        C = ops.gemm_f16(A.to(dev), Bt.to(dev), lib=lib)
+        C = ops.gemm_f16(A.to(dev), Bt.to(dev), lib=lib, tile_cfg=tile_cfg)
         want = A.float() @ Bt.float().T
         assert (C.cpu() - want).abs().max().item() < 2e-3 * (K / 64) ** 0.5, (M, Nn, K)
 

@@ -65,7 +65,10 @@ def test_adam(emu):
 
 def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(100, 128, 64), (130, 256, 192)])
-    K.check_gemm(emu, 'cpu', [(2100, 128, 192)])          # large-M variant (256x128 tile, LDS-DMA staging)
+    K.check_gemm(emu, 'cpu', [(2100, 128, 192)])          # 256x128 tile config
+    K.check_gemm(emu, 'cpu', [(520, 256, 128)])           # 64x64 tile config at a ragged M
+    K.check_gemm(emu, 'cpu', [(300, 256, 192)], tile_cfg=3)   # 256x256 tile config (2-stage ring, chunked epilogue)
+    K.check_gemm(emu, 'cpu', [(70, 128, 64)], tile_cfg=2)     # single k-tile, single partial tile
 
 
 def test_vit(emu):

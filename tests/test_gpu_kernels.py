@@ -71,6 +71,11 @@ def test_gemm_mfma_layout():
     K.check_gemm(None, DEV, [(100, 128, 64), (130, 256, 192), (9500, 768, 768), (1000, 3072, 768), (777, 768, 3072)])
 
 
+def test_gemm_every_tile_config():
+    for cfg in (1, 2, 3):
+        K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
+
+
 def test_vit_tiny():
     K.check_vit(None, DEV)
 

@@ -11,7 +11,7 @@ for (M, N, K) in [(9500, 768, 3072), (9500, 3072, 768), (9500, 768, 768), (8192,
         B = torch.randn(N, K + pad, device='cuda').half()
         C = torch.empty(M, N, device='cuda')
         st = _stream(A)
-        f = lambda: L.call('aph_gemm_f16_ld', ptr(A), K + pad, ptr(B), K + pad, M, N, K, ptr(C), st)
+        f = lambda: L.call('aph_gemm_f16_ld', ptr(A), K + pad, ptr(B), K + pad, M, N, K, ptr(C), 0, st)
         for _ in range(5): f()
         torch.cuda.synchronize()
         n = 30 if M * N * K < 1e11 else 8
