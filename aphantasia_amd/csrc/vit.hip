@@ -123,24 +123,24 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
 
 template <bool OUT_F16, bool CLS>
 void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void* out, int M, int T, const float* cls,
-                   const float* pos, float* x_fill, hipStream_t st) {
+                   const float* pos, float* x_fill, hipStream_t st, int xs = 1) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
-    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
-    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
-    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill); break;
+    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
+    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
+    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
+    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
   }
 }
 template <bool DY_F16, bool PATCH>
 void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const float* res, float* out32, half_t* out16, int M,
-                   int T, hipStream_t st) {
+                   int T, hipStream_t st, int xs = 1) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
-    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
-    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
-    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T); break;
+    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
+    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
+    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
+    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
   }
 }
 
@@ -250,10 +250,14 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
       APH_LAUNCH(attn_fwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
     else
       APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
-    vgemm(v, l.att, D, l.w_o, D, M, D, D, EpiResidual{l.x_mid, l.x_in, D, l.b_o}, st);
-    launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, M, T, nullptr, nullptr, nullptr, st);
-    vgemm(v, v->h, D, l.w_fc1, D, M, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
-    vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, M, D, 4 * D, EpiResidual{x_next, l.x_mid, D, l.b_fc2}, st);
+    // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
+    // its attention runs on the S class rows alone: the same buffers addressed with a row pitch of T rows.
+    const bool cls_only = li + 1 == v->L;
+    const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
+    vgemm(v, l.att, rs * D, l.w_o, D, Mr, D, D, EpiResidual{l.x_mid, l.x_in, rs * D, l.b_o}, st);
+    launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, Mr, T, nullptr, nullptr, nullptr, st, rs);
+    vgemm(v, v->h, D, l.w_fc1, D, Mr, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
+    vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, Mr, D, 4 * D, EpiResidual{x_next, l.x_mid, rs * D, l.b_fc2}, st);
   }
   APH_LAUNCH(head_fwd_kernel, dim3(S, (v->E + 127) / 128), dim3(256), sizeof(float) * (D + 256), st, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
@@ -275,10 +279,13 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];
-    vgemm(v, v->dx16, D, l.w_fc2T, D, M, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
-    vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, M, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
-    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, M, T, st);
-    vgemm(v, v->dx16, D, l.w_oT, D, M, D, D, EpiF16{v->datt, D, nullptr}, st);
+    const bool cls_only = li + 1 == v->L;          // see aph_vit_forward: the last block's MLP / out-proj saw class rows only
+    const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
+    if (cls_only) (void)hipMemsetAsync(v->datt, 0, sizeof(half_t) * (size_t)M * D, st);   // no gradient into the other rows' attention output
+    vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+    vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
+    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);
+    vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
     if (T <= AT_T)
       APH_LAUNCH(attn_bwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
                  (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
@@ -330,11 +337,11 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 }
 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
-// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256 [needs N % 256 == 0]) -- unit tests and layout experiments
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256, 4 = 256x256 phased [both need N % 256 == 0]) -- unit tests and layout experiments
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      tile_cfg < 0 || tile_cfg > 3 || (tile_cfg == 3 && N % 256))
+      tile_cfg < 0 || tile_cfg > 5 || ((tile_cfg == 3 || tile_cfg == 4) && N % 256))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
@@ -343,6 +350,8 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 3) launch_gemm_cfg<GemmHuge>(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 5) launch_gemm_cfg<GemmMid>(A, lda, B, ldb, M, N, K, epi, st);
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH

@@ -50,6 +50,7 @@ struct GemmCfg {
 };
 using GemmHuge = GemmCfg<2, 4, 8, 4, 2, false>;   // 256 x 256, 512 threads, 128 KiB: 128 flop per L2 byte (128 acc VGPRs: one fragment set)
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
+using GemmMid = GemmCfg<2, 2, 4, 4, 2>;      // 128 x 128, 256 threads,  64 KiB (2 workgroups per CU: one's epilogue under the other's main loop)
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
 
 template <class C>
@@ -198,6 +199,174 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
   }
 }
 
+// ---- phased 256x256x64 kernel (cdna_hip_programming.md section 5.5, "8-phase" schedule) ----------------------
+// 8 waves as 2 (M) x 4 (N), 128x64 of C per wave, double-buffered 64 KiB stages.  A k-tile is worked off in FOUR
+// phases, one C quadrant of the wave (64x32, 16 MFMAs over K = 64) each, in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0)
+// so that consecutive phases share one operand's fragments: 24 ds_read_b128 feed 64 MFMAs.  A phase is
+//     { fragment reads + 2 DMA instructions | s_barrier | 16 MFMAs at raised priority | s_barrier }
+// and the waves of the second M half run ONE BARRIER BEHIND the first (`if (wr) s_barrier` up front): the two waves
+// that share a SIMD alternate, one in its MFMA segment while the other issues LDS reads and DMA.
+// The next k-tile streams in as four half-tiles (A0, B0, B1, A1: 16 KiB = 2 DMA instructions per wave each), one per
+// phase, each >= 3 phases ahead of its first read; counted vmcnt(4) keeps the newest two in flight.
+// Hazards.  RAW: the half-tile read in phase p+1 was issued in phase p-2; every wave retires its share (vmcnt(4):
+// only the issues of phases p-1 and p may be outstanding) before the barrier that precedes those reads -- for the
+// leading group that is the phase's second barrier, for the trailing group (one barrier behind) its first.
+// WAR: a stage is refilled during the k-tile after the one it served, >= 2 phases after the trailing group's last
+// read of the half-tile being replaced (B0 is kept in registers for phase 4, so phase 4 reads nothing).
+struct Gemm8 {
+  static constexpr int BM = 256, BN = 256, NTHREAD = 512, NWAVE = 8;
+  static constexpr int STAGE = (BM + BN) * GEMM_BK;      // halfs
+  static constexpr int SMEM = 2 * STAGE * 2;             // bytes (128 KiB)
+  static constexpr int CT_LD = 64 + 4, EP_MT = 2;
+};
+
+__device__ __forceinline__ void phase_barrier(bool wait, bool last) {
+  // `wait`: this wave's DMA shares for the next phase's reads must have landed (see RAW above)
+  if (!wait) wait_vm_barrier<63>();
+  else if (last) wait_vm_barrier<0>();
+  else wait_vm_barrier<4>();
+}
+__device__ __forceinline__ void mfma_prio(int on) {
+#ifndef APH_EMU
+  if (on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+  else { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+#endif
+}
+
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb,
+                                                        int M, int N, int K, Epi epi) {
+  using C = Gemm8;
+  APH_DYN_SMEM(smem);
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntn = N / C::BN;
+    const int tm = tile / ntn;
+    n0 = (tile - tm * ntn) * C::BN;
+    m0 = tm * C::BM;
+  }
+  // DMA shares: half-tile X, instruction i of this wave covers 8 consecutive tile rows starting at row0(X, i)
+  const int lrow = lane >> 3, pc = lane & 7;
+  const half_t* gA[2][2];       // [half][i]
+  const half_t* gB[2];          // [i], half 0; half 1 = + 32 rows
+  int dA[2][2], dB[2][2];       // LDS offsets (halfs) inside a stage
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q0 = (wave * 2 + i) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row0 = (q0 >> 6) * 128 + h * 64 + (q0 & 63), row = row0 + lrow;
+      int am = m0 + row; am = am < M ? am : M - 1;
+      gA[h][i] = A + (size_t)am * lda + ((pc ^ ((row >> 1) & 7)) << 3);
+      dA[h][i] = row0 * GEMM_BK;
+      const int brow0 = (q0 >> 5) * 64 + h * 32 + (q0 & 31);
+      dB[h][i] = C::BM * GEMM_BK + brow0 * GEMM_BK;
+      if (h == 0) gB[i] = Bt + (size_t)(n0 + brow0 + lrow) * ldb + ((pc ^ (((brow0 + lrow) >> 1) & 7)) << 3);
+    }
+  }
+  const size_t bhalf = (size_t)32 * ldb;
+  auto issue_a = [&](int h, int kt, half_t* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(gA[h][i] + kt * GEMM_BK, stage + dA[h][i]);
+  };
+  auto issue_b = [&](int h, int kt, half_t* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(gB[i] + (h ? bhalf : 0) + kt * GEMM_BK, stage + dB[h][i]);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8 fa[4][2], fb[2][2][2];       // A: [row tile][k step] of the current half; B: [half][col tile][k step]
+  const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15), fchunk = lane >> 4;
+  auto read_a = [&](int h, const half_t* stage) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[t][ks] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 16, ks * 4 + fchunk));
+  };
+  auto read_b = [&](int h, const half_t* stage) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        fb[h][t][ks] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32 + t * 16, ks * 4 + fchunk));
+  };
+  auto quadrant = [&](int ah, int bh) {
+    mfma_prio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[ah * 4 + mt][bh * 2 + nt] = mfma_16x16x32_f16(fb[bh][nt][ks], fa[mt][ks], acc[ah * 4 + mt][bh * 2 + nt]);
+    mfma_prio(0);
+  };
+
+  const int nk = K / GEMM_BK;
+  issue_a(0, 0, lds); issue_b(0, 0, lds); issue_b(1, 0, lds); issue_a(1, 0, lds);
+  wait_vm_barrier<0>();
+  const bool lead = wr == 0;
+  if (!lead) wait_vm_barrier<63>();            // trailing group: one barrier behind from here on
+  for (int kt = 0; kt < nk; ++kt) {
+    half_t* cur = lds + (kt & 1) * C::STAGE;
+    half_t* nxt = lds + ((kt + 1) & 1) * C::STAGE;
+    const bool more = kt + 1 < nk;
+    // phase 1: quadrant (A0, B0)
+    read_a(0, cur); read_b(0, cur);
+    if (more) issue_a(0, kt + 1, nxt);
+    phase_barrier(!lead, !more);
+    quadrant(0, 0);
+    phase_barrier(lead, !more);
+    // phase 2: (A0, B1)
+    read_b(1, cur);
+    if (more) issue_b(0, kt + 1, nxt);
+    phase_barrier(!lead, !more);
+    quadrant(0, 1);
+    phase_barrier(lead, !more);
+    // phase 3: (A1, B1)
+    read_a(1, cur);
+    if (more) issue_b(1, kt + 1, nxt);
+    phase_barrier(false, false);
+    quadrant(1, 1);
+    phase_barrier(false, false);
+    // phase 4: (A1, B0) -- nothing to read
+    if (more) issue_a(1, kt + 1, nxt);
+    phase_barrier(!lead, false);
+    quadrant(1, 0);
+    phase_barrier(lead, false);
+  }
+  if (lead) wait_vm_barrier<63>();             // balance the trailing group's extra barrier
+  __syncthreads();
+  float* ct = reinterpret_cast<float*>(smem) + wave * (C::EP_MT * 16 * C::CT_LD);
+#pragma unroll
+  for (int p0 = 0; p0 < 8; p0 += C::EP_MT) {
+    wave_lds_fence();
+#pragma unroll
+    for (int mt = 0; mt < C::EP_MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < C::EP_MT * 2; ++it) {
+      const int r = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
+      const int m = m0 + (wr * 8 + p0) * 16 + r;
+      if (m < M) epi.apply8(m, n0 + wc * 64 + c8, a, b);
+    }
+  }
+}
+
 // ---- epilogues: apply8 gets 8 consecutive columns n..n+7 of row m -------------------------------------------
 __device__ __forceinline__ void store_h4(half_t* p, float a, float b, float c, float d) {
   half4 h = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
@@ -284,6 +453,14 @@ inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb,
   (void)once;
   APH_LAUNCH((gemm_f16_kernel<C, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb,
              M, N, K, epi);
+}
+
+template <class Epi>
+inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM), true);
+  (void)once;
+  APH_LAUNCH((gemm8_f16_kernel<Epi>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A,
+             lda, Bt, ldb, M, N, K, epi);
 }
 
 // tile choice: the 256x128 tile only when it yields enough workgroups to occupy a good part of the chip (measured

@@ -20,7 +20,7 @@ constexpr int kHeadDim = 64;
 template <int NV, bool OUT_F16, bool CLS_FILL>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                               void* __restrict__ out, int M, int T, const float* __restrict__ cls, const float* __restrict__ pos,
-                              float* __restrict__ x_fill) {
+                              float* __restrict__ x_fill, int xs) {
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -34,7 +34,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
       v[i] = *reinterpret_cast<const f32x4*>(cls + d) + *reinterpret_cast<const f32x4*>(pos + d);
       *reinterpret_cast<f32x4*>(x_fill + (size_t)row * D + d) = v[i];
     } else {
-      v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + d);
+      v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * xs * D + d);     // xs: input row stride (T = class rows only)
     }
   }
   float s = 0.f;
@@ -70,16 +70,18 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // (feeds the patch-embedding dgrad GEMM).
 template <int NV, bool DY_F16, bool PATCH_ROWS>
 __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                              const float* __restrict__ res, float* __restrict__ out32, half_t* __restrict__ out16, int M, int T) {
+                              const float* __restrict__ res, float* __restrict__ out32, half_t* __restrict__ out16, int M, int T,
+                              int xs) {
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
+  const size_t srow = (size_t)row * xs;       // x / res / outputs live at row stride xs (T = class rows only); dy is compact
   f32x4 v[NV], g[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int d = i * 256 + lane * 4;
-    v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + d);
+    v[i] = *reinterpret_cast<const f32x4*>(x + srow * D + d);
     f32x4 dyv;
     if (DY_F16) {
       const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(dy) + (size_t)row * D + d);
@@ -106,7 +108,7 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
     for (int j = 0; j < 4; ++j) { v[i][j] *= rstd; sg += g[i][j]; sgx += g[i][j] * v[i][j]; }
   sg = wave_sum(sg) * (1.0f / D);
   sgx = wave_sum(sgx) * (1.0f / D);
-  int orow = row;
+  size_t orow = srow;
   if (PATCH_ROWS) {
     const int s_ = row / T, t_ = row - s_ * T;
     if (t_ == 0) return;
@@ -118,11 +120,11 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - sg - v[i][j] * sgx);
-    if (res) o += *reinterpret_cast<const f32x4*>(res + (size_t)row * D + d);
-    if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)row * D + d) = o;
+    if (res) o += *reinterpret_cast<const f32x4*>(res + srow * D + d);
+    if (out32) *reinterpret_cast<f32x4*>(out32 + srow * D + d) = o;
     if (out16) {
       half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-      *reinterpret_cast<half4*>(out16 + (size_t)orow * D + d) = h;
+      *reinterpret_cast<half4*>(out16 + orow * D + d) = h;
     }
   }
 }
