@@ -146,6 +146,13 @@ void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const
 
 }  // namespace
 
+struct EpiProbe {        // experiment: full epilogue data path, stores predicated off at run time
+  float* out; int ldo; float on;
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    if (on != 0.f) { st4(out + (size_t)m * ldo + n, a); st4(out + (size_t)m * ldo + n + 4, b); }
+  }
+};
+
 extern "C" {
 
 // cfg mirrors clip.model.VisionTransformer(input_resolution, patch_size, width, layers, heads, output_dim)
@@ -341,7 +348,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      tile_cfg < 0 || tile_cfg > 5 || ((tile_cfg == 3 || tile_cfg == 4) && N % 256))
+      tile_cfg < 0 || tile_cfg > 40 || ((tile_cfg == 3 || tile_cfg == 4) && N % 256))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
@@ -352,6 +359,13 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 3) launch_gemm_cfg<GemmHuge>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 5) launch_gemm_cfg<GemmMid>(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 6) launch_gemm8(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 11) launch_gemm8<EpiProbe, 1>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 12) launch_gemm8<EpiProbe, 2>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 13) launch_gemm8<EpiProbe, 3>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 17) launch_gemm8<EpiProbe, 7>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 18) launch_gemm8<EpiProbe, 8>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 7) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH

@@ -220,6 +220,13 @@ struct Gemm8 {
   static constexpr int CT_LD = 64 + 4, EP_MT = 2;
 };
 
+template <int ABL = 0>
+__device__ __forceinline__ void phase_barrier_t(bool wait, bool last) {
+  if (ABL & 4) return;
+  if (!wait) wait_vm_barrier<63>();
+  else if (last) wait_vm_barrier<0>();
+  else wait_vm_barrier<4>();
+}
 __device__ __forceinline__ void phase_barrier(bool wait, bool last) {
   // `wait`: this wave's DMA shares for the next phase's reads must have landed (see RAW above)
   if (!wait) wait_vm_barrier<63>();
@@ -233,7 +240,7 @@ __device__ __forceinline__ void mfma_prio(int on) {
 #endif
 }
 
-template <class Epi>
+template <class Epi, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb,
                                                         int M, int N, int K, Epi epi) {
   using C = Gemm8;
@@ -272,10 +279,12 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
   }
   const size_t bhalf = (size_t)32 * ldb;
   auto issue_a = [&](int h, int kt, half_t* stage) {
+    if ((ABL & 1) && kt > 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(gA[h][i] + kt * GEMM_BK, stage + dA[h][i]);
   };
   auto issue_b = [&](int h, int kt, half_t* stage) {
+    if ((ABL & 1) && kt > 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(gB[i] + (h ? bhalf : 0) + kt * GEMM_BK, stage + dB[h][i]);
   };
@@ -287,13 +296,16 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   half8 fa[4][2], fb[2][2][2];       // A: [row tile][k step] of the current half; B: [half][col tile][k step]
   const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15), fchunk = lane >> 4;
+  bool first = true;
   auto read_a = [&](int h, const half_t* stage) {
+    if ((ABL & 2) && !first) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) fa[t][ks] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 16, ks * 4 + fchunk));
   };
   auto read_b = [&](int h, const half_t* stage) {
+    if ((ABL & 2) && !first) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -301,14 +313,14 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
         fb[h][t][ks] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32 + t * 16, ks * 4 + fchunk));
   };
   auto quadrant = [&](int ah, int bh) {
-    mfma_prio(1);
+    if (!(ABL & 8)) mfma_prio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[ah * 4 + mt][bh * 2 + nt] = mfma_16x16x32_f16(fb[bh][nt][ks], fa[mt][ks], acc[ah * 4 + mt][bh * 2 + nt]);
-    mfma_prio(0);
+    if (!(ABL & 8)) mfma_prio(0);
   };
 
   const int nk = K / GEMM_BK;
@@ -323,26 +335,27 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
     // phase 1: quadrant (A0, B0)
     read_a(0, cur); read_b(0, cur);
     if (more) issue_a(0, kt + 1, nxt);
-    phase_barrier(!lead, !more);
+    phase_barrier_t<ABL>(!lead, !more);
     quadrant(0, 0);
-    phase_barrier(lead, !more);
+    phase_barrier_t<ABL>(lead, !more);
     // phase 2: (A0, B1)
     read_b(1, cur);
     if (more) issue_b(0, kt + 1, nxt);
-    phase_barrier(!lead, !more);
+    phase_barrier_t<ABL>(!lead, !more);
     quadrant(0, 1);
-    phase_barrier(lead, !more);
+    phase_barrier_t<ABL>(lead, !more);
     // phase 3: (A1, B1)
     read_a(1, cur);
     if (more) issue_b(1, kt + 1, nxt);
-    phase_barrier(false, false);
+    phase_barrier_t<ABL>(false, false);
     quadrant(1, 1);
-    phase_barrier(false, false);
+    phase_barrier_t<ABL>(false, false);
     // phase 4: (A1, B0) -- nothing to read
     if (more) issue_a(1, kt + 1, nxt);
-    phase_barrier(!lead, false);
+    phase_barrier_t<ABL>(!lead, false);
     quadrant(1, 0);
-    phase_barrier(lead, false);
+    phase_barrier_t<ABL>(lead, false);
+    first = false;
   }
   if (lead) wait_vm_barrier<63>();             // balance the trailing group's extra barrier
   __syncthreads();
@@ -455,11 +468,11 @@ inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb,
              M, N, K, epi);
 }
 
-template <class Epi>
+template <class Epi, int ABL = 0>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM), true);
+  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, ABL>), Gemm8::SMEM), true);
   (void)once;
-  APH_LAUNCH((gemm8_f16_kernel<Epi>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A,
+  APH_LAUNCH((gemm8_f16_kernel<Epi, ABL>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A,
              lda, Bt, ldb, M, N, K, epi);
 }
 
@@ -469,7 +482,7 @@ template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
   const int huge_tiles = (N / GemmHuge::BN) * ((M + GemmHuge::BM - 1) / GemmHuge::BM);
-  if (N % GemmHuge::BN == 0 && huge_tiles >= 400) launch_gemm_cfg<GemmHuge>(A, lda, Bt, ldb, M, N, K, epi, st);
+  if (N % GemmHuge::BN == 0 && huge_tiles >= 400) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (big_tiles >= 96) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
 }

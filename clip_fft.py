@@ -111,32 +111,42 @@ def derate_samples(a):
 
 
 class FrameWriter:
-    """Background JPEG writer: the reference encodes every frame synchronously on the hot loop (clip_fft.py:297-306)."""
+    """Background JPEG writers: the reference converts and encodes every frame synchronously inside the hot loop
+    (clip_fft.py:297-306, utils.py:94-100).  Here the loop only enqueues a device-side uint8 conversion and an async
+    copy into a pinned ring; a small thread pool waits for the copy event and encodes (PIL releases the GIL)."""
+    THREADS = 4
+    RING = 16          # > queue depth + THREADS: a pinned buffer is never rewritten while a writer still reads it
 
-    def __init__(self):
+    def __init__(self, h, w):
         self.q = queue.Queue(maxsize=8)
-        self.t = threading.Thread(target=self._run, daemon=True)
-        self.t.start()
+        self.bufs = [torch.empty(h, w, 3, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.n = 0
+        self.ts = [threading.Thread(target=self._run, daemon=True) for _ in range(self.THREADS)]
+        for t in self.ts: t.start()
 
     def _run(self):
-        from aphantasia_amd.utils import checkout
+        from PIL import Image
         while True:
             item = self.q.get()
             if item is None:
                 return
-            img, ev, fname, gamma = item
+            buf, ev, fname = item
             ev.synchronize()
-            arr = img.numpy()
-            if gamma != 1.0:
-                arr = arr ** gamma
-            checkout(arr, fname)
+            Image.fromarray(buf.numpy()).save(fname, quality=95)
 
-    def put(self, img_host, event, fname, gamma):
-        self.q.put((img_host, event, fname, gamma))
+    def put(self, img, fname, gamma=1.0):
+        """img: device float [3,H,W] in [0,1]; same arithmetic as utils.checkout: clip(img*255, 0, 255).astype(uint8)"""
+        if gamma != 1.0:
+            img = img ** gamma
+        buf = self.bufs[self.n % self.RING]
+        self.n += 1
+        buf.copy_((img * 255).clamp_(0, 255).to(torch.uint8).permute(1, 2, 0), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        self.q.put((buf, ev, fname))
 
     def close(self):
-        self.q.put(None)
-        self.t.join()
+        for _ in self.ts: self.q.put(None)
+        for t in self.ts: t.join()
 
 
 def main(argv=None):
@@ -246,8 +256,7 @@ def main(argv=None):
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                       optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), **pk)
 
-    writer = None if a.no_save else FrameWriter()
-    host_bufs = [torch.empty(3, h, w).pin_memory() for _ in range(4)]
+    writer = None if a.no_save else FrameWriter(h, w)
     gamma = 1.0
     t0 = time.time()
     for i in range(a.steps):
@@ -259,10 +268,7 @@ def main(argv=None):
         e.step(lr=lr_cur, shift=shift)
         if i % a.opt_step == 0 and writer is not None:
             img = e.synthesize(a.contrast)                                              # clip_fft.py:298-299
-            buf = host_bufs[(i // a.opt_step) % len(host_bufs)]
-            buf.copy_(img, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-            writer.put(buf, ev, os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)
+            writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)
         if a.verbose and (i % 10 == 9 or i == a.steps - 1):
             print(' step %d/%d  loss %.4f  %.1f steps/s' % (i + 1, a.steps, e.global_loss(), (i + 1) / (time.time() - t0)), flush=True)
     torch.cuda.synchronize()
