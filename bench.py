@@ -138,9 +138,20 @@ def main():
         lib.call('aph_vit_profile', h_.handle, 0)
         if n.value > 0:
             achieved = flops.value / (ms.value * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='aph::gemm_f16_kernel<*>', achieved=achieved, peak=2500.0, unit='TFLOP/s',
-                        frac=achieved / 2500.0, traffic=None, launches_per_step=n.value // min(a.steps, 10),
-                        avg_launch_us=ms.value * 1e3 / n.value, flops_per_launch=flops.value / n.value)
+            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (a PMC pass cannot run inside this process);
+            # the committed summary of the latest pass is quoted when the workload is the one it was taken on
+            traffic, tsrc = None, None
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_*.json')))
+            if pm and (w, h, a.model, a.samples, a.transform) == (1280, 720, 'ViT-B/32', 200, 'fast') and world == 1:
+                with open(pm[-1]) as f:
+                    traffic = json.load(f)['traffic_bytes_per_launch']
+                tsrc = os.path.relpath(pm[-1], ROOT)
+            roof = dict(bound='mfma', kernel='aph::gemm_f16_kernel<*> / aph::gemm8_f16_kernel<*>', achieved=achieved, peak=2500.0,
+                        unit='TFLOP/s', frac=achieved / 2500.0, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
+                        traffic_source=tsrc, launches_per_step=n.value // min(a.steps, 10),
+                        avg_launch_us=ms.value * 1e3 / n.value, flops_per_launch=flops.value / n.value,
+                        peak_measured_random_operands=1800.0)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(w, h, a.model, S)
