@@ -40,6 +40,7 @@ struct aph_vit {
   half_t *h = nullptr, *gact = nullptr;
   float* dx = nullptr;
   half_t *dx16 = nullptr, *du = nullptr, *dh = nullptr, *datt = nullptr, *dqkv = nullptr, *dx0_16 = nullptr;
+  SplitKSpace sk;                      // split-K partials of the small-M GEMMs (per-rank shards, class-row GEMMs)
   char* arena = nullptr;
   size_t arena_bytes = 0;
   int n_set = 0;
@@ -84,6 +85,8 @@ void carve(aph_vit* v, char* base, size_t* total) {
   v->dx = c.take<float>(Mx * D);
   v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
   v->datt = c.take<half_t>(Mx * D); v->dqkv = c.take<half_t>(Mx * 3 * D); v->dx0_16 = c.take<half_t>(Mx * D);
+  v->sk.ws_floats = (size_t)256 * GemmSmall::BM * GemmSmall::BN;       // choose_splits keeps tiles * splits <= 256
+  v->sk.ws = c.take<float>(v->sk.ws_floats);
   *total = c.off;
 }
 
@@ -108,14 +111,14 @@ int upload_f32(float* dst, const float* src, size_t rows, size_t cols, bool tran
 
 template <class Epi>
 void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  if (!v->prof_on) { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st); return; }
+  if (!v->prof_on) { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); return; }
   if (v->prof_used + 2 > v->prof_ev.size()) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     v->prof_ev.push_back(a); v->prof_ev.push_back(b);
   }
   (void)hipEventRecord(v->prof_ev[v->prof_used], st);
-  launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st);
+  launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk);
   (void)hipEventRecord(v->prof_ev[v->prof_used + 1], st);
   v->prof_used += 2;
   v->prof_flops += 2.0 * M * N * K;
@@ -344,7 +347,8 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 }
 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
-// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256, 4 = 256x256 phased [both need N % 256 == 0]) -- unit tests and layout experiments
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256, 4 = 256x256 phased [both need N % 256 == 0], 5 = 128x128 2-stage,
+// 8 / 9 = 64x64 split-K x2 / x4, 10 = 128x128 4-stage; other codes are measurement variants used by tools/) -- unit tests and layout experiments
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
@@ -365,6 +369,17 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 13) launch_gemm8<EpiProbe, 3>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else if (tile_cfg == 17) launch_gemm8<EpiProbe, 7>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else if (tile_cfg == 18) launch_gemm8<EpiProbe, 8>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
+  else if (tile_cfg == 8 || tile_cfg == 9) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
+    static SplitKSpace sp;
+    const int splits = tile_cfg == 8 ? 2 : 4;
+    if (K / GEMM_BK < splits || (size_t)M * N > ((size_t)1 << 24)) return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: shape not usable with split-K");
+    if (!sp.ws) {
+      sp.ws_floats = (size_t)4 << 24;
+      if (hipMalloc((void**)&sp.ws, sp.ws_floats * sizeof(float)) != hipSuccess) return aph_fail(APH_ERR_HIP, "aph_gemm_f16_ld: split-K workspace");
+    }
+    launch_gemm_splitk(A, lda, B, ldb, M, N, K, epi, splits, sp, st);
+  }
+  else if (tile_cfg == 10) launch_gemm_cfg<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 7) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");

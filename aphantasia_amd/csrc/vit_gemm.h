@@ -51,6 +51,7 @@ struct GemmCfg {
 using GemmHuge = GemmCfg<2, 4, 8, 4, 2, false>;   // 256 x 256, 512 threads, 128 KiB: 128 flop per L2 byte (128 acc VGPRs: one fragment set)
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmMid = GemmCfg<2, 2, 4, 4, 2>;      // 128 x 128, 256 threads,  64 KiB (2 workgroups per CU: one's epilogue under the other's main loop)
+using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
 
 template <class C>
@@ -81,20 +82,32 @@ __device__ __forceinline__ void ring_wait(int ahead) {
   else wait_vm_barrier<2 * C::GPT>();
 }
 
-template <class C, class Epi>
+// Split-K (latency-bound shapes: small M, long K): `splits` workgroups share one output tile, each running a contiguous
+// share of the k-tiles and writing its fp32 partial tile to ws[split][M][N]; a second small kernel sums the partials in
+// split order 0..splits-1 (fixed order: bitwise reproducible) and applies the epilogue.  The kernel boundary is the
+// synchronisation: an in-kernel ticket scheme needs an agent-scope release per workgroup, which on this part writes back
+// the whole L2 (measured 0.2 us per workgroup, serialised: 100-1000 us per launch).
+struct SplitK {
+  float* ws;          // [splits][M][N] floats
+  int splits;
+};
+
+template <class C, class Epi, bool SK = false>
 __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
-                                                              int ldb, int M, int N, int K, Epi epi) {
+                                                              int ldb, int M, int N, int K, Epi epi, SplitK sk) {
   APH_DYN_SMEM(smem);
   half_t* lds = reinterpret_cast<half_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave - wm * C::WN;
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, speed only).  Every XCD gets one contiguous
   // run of tiles, n-tiles fastest.  Bijective for any grid size.
-  int m0, n0;
+  int m0, n0, tile_id = 0, split = 0;
   {
-    const int nwg = gridDim.x, b = blockIdx.x;
+    int nwg = gridDim.x, b = blockIdx.x;
+    if (SK) { split = b % sk.splits; b /= sk.splits; nwg /= sk.splits; }
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_id = tile;
     const int ntn = N / C::BN;
     const int tm = tile / ntn;
     n0 = (tile - tm * ntn) * C::BN;
@@ -115,10 +128,15 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     const int row = (wave * C::GB + k) * 8 + lrow;
     gb[k] = Bt + (size_t)(n0 + row) * ldb + ((pc ^ ((row >> 1) & 7)) << 3);
   }
+  int kbeg = 0, nk = K / GEMM_BK;
+  if (SK) {
+    kbeg = (int)((long long)nk * split / sk.splits);
+    nk = (int)((long long)nk * (split + 1) / sk.splits) - kbeg;
+  }
   auto issue = [&](int kt, int stage) {
     half_t* As = lds + stage * C::STAGE;
     half_t* Bs = As + C::BM * GEMM_BK;
-    const int ko = kt * GEMM_BK;
+    const int ko = (kbeg + kt) * GEMM_BK;
 #pragma unroll
     for (int k = 0; k < C::GA; ++k) glds16(ga[k] + ko, As + (wave * C::GA + k) * 8 * GEMM_BK);
 #pragma unroll
@@ -131,7 +149,6 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / GEMM_BK;
   const int arow = wm * C::TM * 16 + (lane & 15), brow = wn * C::TN * 16 + (lane & 15), fchunk = lane >> 4;
   // Ring protocol, tile t lives in stage t % NSTAGE.  Per tile kt: own DMAs of tile kt retired (counted vmcnt: newer
   // tiles stay in flight) -> s_barrier (everyone's retired; everyone's fragment reads of tile kt-1 are complete, so
@@ -194,9 +211,34 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
       const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
       const int m = m0 + (wm * C::TM + p0) * 16 + r;
-      if (m < M) epi.apply8(m, n0 + wn * C::TN * 16 + c8, a, b);
+      if (m < M) {
+        if (SK) {
+          float* o = sk.ws + ((size_t)split * M + m) * N + n0 + wn * C::TN * 16 + c8;
+          *reinterpret_cast<f32x4*>(o) = a;
+          *reinterpret_cast<f32x4*>(o + 4) = b;
+        } else {
+          epi.apply8(m, n0 + wn * C::TN * 16 + c8, a, b);
+        }
+      }
     }
   }
+}
+
+// second pass of split-K: thread = 8 consecutive columns of one row
+template <class Epi>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi epi) {
+  const int n8 = N >> 3;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * n8) return;
+  const int m = (int)(idx / n8), n = (int)(idx - (size_t)m * n8) * 8;
+  const float* p = ws + (size_t)m * N + n;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  for (int sp = 1; sp < splits; ++sp) {
+    p += (size_t)M * N;
+    a += *reinterpret_cast<const f32x4*>(p);
+    b += *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  epi.apply8(m, n, a, b);
 }
 
 // ---- phased 256x256x64 kernel (cdna_hip_programming.md section 5.5, "8-phase" schedule) ----------------------
@@ -462,29 +504,71 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
 
 template <class C, class Epi>
 inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi>), C::SMEM), true);
+  static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false>), C::SMEM), true);
   (void)once;
-  APH_LAUNCH((gemm_f16_kernel<C, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb,
-             M, N, K, epi);
+  APH_LAUNCH((gemm_f16_kernel<C, Epi, false>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt,
+             ldb, M, N, K, epi, SplitK{nullptr, 1});
+}
+
+// split-K workspace of one caller (the ViT handle owns one; the partials of a launch are consumed by the reduce kernel
+// that follows it on the same stream)
+struct SplitKSpace {
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+};
+
+// how many ways to split K for the 64x64 configuration: only when the tiles alone occupy a small part of the chip (the
+// class-row GEMMs: M = cuts) and the k loop is long; every share keeps >= 6 k-tiles.  At M ~ 1200 (228 tiles) the
+// 64x64 tiles are bound by L2-miss bandwidth on the weight panel, and splitting K was measured to lose (18 -> 21 us).
+inline int choose_splits(int M, int N, int K, const SplitKSpace* sp) {
+  if (!sp || !sp->ws) return 1;
+  const int tiles = (N / GemmSmall::BN) * ((M + GemmSmall::BM - 1) / GemmSmall::BM), nk = K / GEMM_BK;
+  int splits = 1;
+  while (splits < 4 && tiles * (splits * 2) <= 256 && nk / (splits * 2) >= 6) splits *= 2;
+  if ((size_t)splits * M * N > sp->ws_floats) return 1;
+  return splits;
+}
+
+template <class Epi>
+inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, int splits,
+                               const SplitKSpace& sp, hipStream_t st) {
+  using C = GemmSmall;
+  static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true>), C::SMEM), true);
+  (void)once;
+  const int tiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
+  APH_LAUNCH((gemm_f16_kernel<C, Epi, true>), dim3(tiles * splits), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi,
+             SplitK{sp.ws, splits});
+  const size_t work = (size_t)M * (N / 8);
+  APH_LAUNCH((splitk_reduce_kernel<Epi>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (const float*)sp.ws, splits, M, N, epi);
 }
 
 template <class Epi, int ABL = 0>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
   static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, ABL>), Gemm8::SMEM), true);
   (void)once;
-  APH_LAUNCH((gemm8_f16_kernel<Epi, ABL>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A,
-             lda, Bt, ldb, M, N, K, epi);
+  APH_LAUNCH((gemm8_f16_kernel<Epi, ABL>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st,
+             A, lda, Bt, ldb, M, N, K, epi);
 }
 
-// tile choice: the 256x128 tile only when it yields enough workgroups to occupy a good part of the chip (measured
-// crossover on the ViT shapes: ~100 tiles; below that the 64x64 tile with 2 workgroups per CU wins)
+// tile choice, from the measured sweep over the ViT-B shapes at 1/2/4/8-rank shard sizes (tools/exp/tune_table.py):
+//   256x256 phased   wide outputs with >= 400 such tiles (N >= 2304 at full batch)
+//   256x128          >= 160 tiles
+//   128x128, 8 waves, 4-stage ring   >= 160 such tiles (half-batch shards with N = 768, wide outputs of small shards)
+//   64x64 (2 workgroups per CU)      everything smaller; split-K when only a handful of tiles exist
 template <class Epi>
-inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
+                        const SplitKSpace* sp = nullptr) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
   const int huge_tiles = (N / GemmHuge::BN) * ((M + GemmHuge::BM - 1) / GemmHuge::BM);
+  const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
   if (N % GemmHuge::BN == 0 && huge_tiles >= 400) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
-  else if (big_tiles >= 96) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
-  else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
+  else if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
+  else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
+  else {
+    const int splits = choose_splits(M, N, K, sp);
+    if (splits > 1) launch_gemm_splitk(A, lda, Bt, ldb, M, N, K, epi, splits, *sp, st);
+    else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
+  }
 }
 
 }  // namespace aph

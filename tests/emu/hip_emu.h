@@ -59,6 +59,7 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return 0; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
@@ -220,6 +221,7 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline void __threadfence() {}
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -72,8 +72,23 @@ def test_gemm_mfma_layout():
 
 
 def test_gemm_every_tile_config():
-    for cfg in (1, 2, 3, 4, 5):
+    for cfg in (1, 2, 3, 4, 5, 10):
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
+
+
+def test_gemm_splitk_matches_and_is_deterministic():
+    """split-K (tile_cfg 8 / 9): ordered last-block reduction -> same bits on every run, fp32-rounding close to the unsplit kernel"""
+    import torch
+    from aphantasia_amd import ops
+    K.check_gemm(None, DEV, [(1200, 768, 3072), (190, 768, 3072), (1200, 768, 2304), (77, 128, 512)], tile_cfg=9)
+    K.check_gemm(None, DEV, [(2400, 768, 3072), (333, 256, 192)], tile_cfg=8)
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(1200, 3072, generator=g).half().to(DEV); Bt = torch.randn(768, 3072, generator=g).half().to(DEV)
+    ref = ops.gemm_f16(A, Bt, tile_cfg=9).clone()
+    for _ in range(20):
+        assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=9), ref)
+    one = ops.gemm_f16(A, Bt, tile_cfg=1)
+    assert (one - ref).abs().max().item() < 2e-3 * one.abs().max().item()
 
 
 def test_vit_tiny():

@@ -1,16 +1,15 @@
-"""Experiment: fixed vs per-k-tile cost of the GEMM configs at shard-sized M."""
+"""Experiment: best tile configuration per (M, N, K) of the ViT-B linears at shard sizes (1, 2, 4, 8 ranks of C2)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aphantasia_amd import _ffi
 from aphantasia_amd.ops import ptr, _stream
 L = _ffi.lib()
-g = torch.cuda.CUDAGraph()
-for M in (190, 1200, 2400):
-  for N in (768, 3072):
-    for K in (768, 2304, 3072):
+for M in (1200, 2400, 4750, 9500):
+    for (N, K) in ((768, 768), (2304, 768), (3072, 768), (768, 2304), (768, 3072)):
         A = torch.randn(M, K, device='cuda').half(); B = torch.randn(N, K, device='cuda').half(); C = torch.empty(M, N, device='cuda')
         line = 'M %5d N %5d K %5d:' % (M, N, K)
-        for cfg in (1, 8, 9, 5):
+        best = None
+        for cfg in (0, 1, 5, 20, 21, 2):
             s = torch.cuda.Stream()
             with torch.cuda.stream(s):
                 st = _stream(A)
@@ -19,7 +18,9 @@ for M in (190, 1200, 2400):
                 s.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
-                for _ in range(50): f()
+                for _ in range(30): f()
                 e1.record(s); s.synchronize()
-            line += '  cfg%d %6.1f us' % (cfg, e0.elapsed_time(e1) / 50 * 1e3)
-        print(line)
+            us = e0.elapsed_time(e1) / 30 * 1e3
+            line += '  cfg%d %6.1f' % (cfg, us)
+            if cfg and (best is None or us < best[1]): best = (cfg, us)
+        print(line + '   best cfg%d' % best[0])
