@@ -39,6 +39,7 @@ struct aph_vit {
   float *x0 = nullptr, *x_last = nullptr;
   half_t *h = nullptr, *gact = nullptr;
   float* dx = nullptr;
+  float* delta = nullptr;              // attention backward row dots dO_i . O_i (T > 64 path)
   half_t *dx16 = nullptr, *du = nullptr, *dh = nullptr, *datt = nullptr, *dqkv = nullptr, *dx0_16 = nullptr;
   SplitKSpace sk;                      // split-K partials of the small-M GEMMs (per-rank shards, class-row GEMMs)
   char* arena = nullptr;
@@ -83,6 +84,7 @@ void carve(aph_vit* v, char* base, size_t* total) {
   v->x0 = c.take<float>(Mx * D); v->x_last = c.take<float>(Mx * D);
   v->h = c.take<half_t>(Mx * D); v->gact = c.take<half_t>(Mx * 4 * D);
   v->dx = c.take<float>(Mx * D);
+  v->delta = c.take<float>((size_t)v->max_batch * v->heads * T);
   v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
   v->datt = c.take<half_t>(Mx * D); v->dqkv = c.take<half_t>(Mx * 3 * D); v->dx0_16 = c.take<half_t>(Mx * D);
   v->sk.ws_floats = (size_t)256 * GemmSmall::BM * GemmSmall::BN;       // choose_splits keeps tiles * splits <= 256
@@ -147,6 +149,41 @@ void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const
   }
 }
 
+// attention launches: T <= 64 one-tile kernels, 64 < T <= 256 the blocked kernels (NB = ceil(T / 64))
+template <int NB>
+void launch_attn_fwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * NB * 8192;
+  static bool once = (APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem), true);
+  (void)once;
+  APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem, st, (const half_t*)l.qkv, l.att, l.lse, v->T, v->heads);
+}
+template <int NB>
+void launch_attn_bwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+  constexpr size_t smem_q = (size_t)3 * NB * 8192, smem_kv = (size_t)4 * NB * 8192 + 2 * NB * 64 * sizeof(float);
+  static bool once = (APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q), APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv), true);
+  (void)once;
+  APH_LAUNCH((attn_bwd_dq_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_q, st, (const half_t*)l.qkv, (const half_t*)l.att,
+             (const half_t*)v->datt, (const float*)l.lse, v->delta, v->dqkv, v->T, v->heads);
+  APH_LAUNCH((attn_bwd_dkv_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_kv, st, (const half_t*)l.qkv, (const half_t*)v->datt,
+             (const float*)l.lse, (const float*)v->delta, v->dqkv, v->T, v->heads);
+}
+void launch_attn_fwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+  const int T = v->T;
+  if (T <= AT_T) APH_LAUNCH(attn_fwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
+  else if (T <= 128) launch_attn_fwd_g<2>(v, l, S, st);
+  else if (T <= 192) launch_attn_fwd_g<3>(v, l, S, st);
+  else launch_attn_fwd_g<4>(v, l, S, st);
+}
+void launch_attn_bwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+  const int T = v->T;
+  if (T <= AT_T)
+    APH_LAUNCH(attn_bwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
+               (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+  else if (T <= 128) launch_attn_bwd_g<2>(v, l, S, st);
+  else if (T <= 192) launch_attn_bwd_g<3>(v, l, S, st);
+  else launch_attn_bwd_g<4>(v, l, S, st);
+}
+
 }  // namespace
 
 struct EpiProbe {        // experiment: full epilogue data path, stores predicated off at run time
@@ -179,9 +216,6 @@ int aph_vit_create(int input_resolution, int patch_size, int width, int layers, 
   if (me != hipSuccess) { delete v; return aph_fail(APH_ERR_HIP, "aph_vit_create: cannot allocate %zu bytes (%s)", total, hipGetErrorString(me)); }
   v->arena_bytes = total;
   carve(v, v->arena, &total);
-  const size_t bwd_smem = (size_t)4 * v->T * 128 + 8 * v->T;
-  APH_ALLOW_SMEM(attn_bwd_kernel, bwd_smem);
-  APH_ALLOW_SMEM(attn_fwd_kernel, (size_t)2 * v->T * 128);
   *out = v;
   return APH_OK;
   APH_CATCH
@@ -256,10 +290,7 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
     launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
     vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
-    if (T <= AT_T)
-      APH_LAUNCH(attn_fwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
-    else
-      APH_LAUNCH(attn_fwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)2 * T * 128, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
+    launch_attn_fwd(v, l, S, st);
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
     // its attention runs on the S class rows alone: the same buffers addressed with a row pitch of T rows.
     const bool cls_only = li + 1 == v->L;
@@ -296,12 +327,7 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);
     vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
-    if (T <= AT_T)
-      APH_LAUNCH(attn_bwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
-                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
-    else
-      APH_LAUNCH(attn_bwd_kernel, dim3(S * v->heads), dim3(((T + 63) / 64) * 64), (size_t)4 * T * 128 + 8 * T, st, (const half_t*)l.qkv,
-                 (const half_t*)l.att, (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+    launch_attn_bwd(v, l, S, st);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
   }
@@ -369,15 +395,16 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 13) launch_gemm8<EpiProbe, 3>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else if (tile_cfg == 17) launch_gemm8<EpiProbe, 7>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else if (tile_cfg == 18) launch_gemm8<EpiProbe, 8>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 8 || tile_cfg == 9) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
+  else if (tile_cfg == 8 || tile_cfg == 9 || tile_cfg == 22 || tile_cfg == 24) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
     static SplitKSpace sp;
-    const int splits = tile_cfg == 8 ? 2 : 4;
+    const int splits = (tile_cfg == 8 || tile_cfg == 22) ? 2 : 4;
     if (K / GEMM_BK < splits || (size_t)M * N > ((size_t)1 << 24)) return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: shape not usable with split-K");
     if (!sp.ws) {
       sp.ws_floats = (size_t)4 << 24;
       if (hipMalloc((void**)&sp.ws, sp.ws_floats * sizeof(float)) != hipSuccess) return aph_fail(APH_ERR_HIP, "aph_gemm_f16_ld: split-K workspace");
     }
-    launch_gemm_splitk(A, lda, B, ldb, M, N, K, epi, splits, sp, st);
+    if (tile_cfg >= 22) launch_gemm_splitk<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, splits, sp, st);
+    else launch_gemm_splitk<GemmSmall>(A, lda, B, ldb, M, N, K, epi, splits, sp, st);
   }
   else if (tile_cfg == 10) launch_gemm_cfg<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 7) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);

@@ -249,4 +249,248 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Same scheme for 64 < T <= 256 tokens (ViT-B/16: T = 197), NB = ceil(T / 64) blocks of 64 tokens, 8 waves.
+// Row-major operand images are [NB*64][64] (at_off on the global row), transposed slot-permuted images are NB tiles
+// of [64 d][64 slots]; probabilities / dS of a 32-token block are one B fragment, so the second product streams over
+// 32-token blocks.  The forward keeps a query tile's whole score row in registers (<= 16 tiles) -- exact softmax, no
+// online rescaling.  The backward is two kernels so that each fits LDS: dQ with K, V, K^T resident (query tiles
+// stationary per wave, Q / dO fragments straight from global) and dK/dV with Q, dO, Q^T, dO^T resident (key tiles
+// stationary); both recompute P = exp(S/8 - lse) per 32-block from the saved log-sum-exp.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void atg_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed, int idx) {
+  const int blk = idx >> 6, item = idx & 63;
+  at_stage_item(src + (size_t)blk * 64 * ld, ld, T - blk * 64, item, rowmajor ? rowmajor + blk * 4096 : nullptr,
+                transposed ? transposed + blk * 4096 : nullptr);
+}
+
+__device__ __forceinline__ half8 ld_frag_global(const half_t* __restrict__ p, bool ok) {
+  const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? *reinterpret_cast<const half8*>(p) : z;
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att,
+                                                             float* __restrict__ lse, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vt = Ks + NB * 4096;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
+    if (idx < NB * 64) atg_stage<NB>(base + D, ld, T, Ks, nullptr, idx);
+    else atg_stage<NB>(base + 2 * D, ld, T, nullptr, Vt, idx - NB * 64);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  for (int it = wave; it * 16 < T; it += 8) {
+    const int i = it * 16 + c16;
+    half8 qf[2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) qf[kd] = ld_frag_global(base + (size_t)i * ld + kd * 32 + g * 8, i < T);
+    f32x4 st[4 * NB];
+#pragma unroll
+    for (int jt = 0; jt < 4 * NB; ++jt) {
+      st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (jt * 16 < T) {
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) st[jt] = mfma_16x16x32_f16(at_frag(Ks, jt * 16 + c16, kd * 4 + g), qf[kd], st[jt]);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = jt * 16 + g * 4 + r < T;
+        st[jt][r] = ok ? st[jt][r] * 0.125f : -1e30f;
+        mx = fmaxf(mx, st[jt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4 * NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] - mx) : 0.f;
+        st[jt][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2 * NB; ++kb) {
+      if (kb * 32 < T) {
+        const half8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_16x16x32_f16(at_frag(Vt + (kb >> 1) * 4096, dt * 16 + c16, (kb & 1) * 4 + g), pf, o[dt]);
+      }
+    }
+    if (i < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        store_h4(att + ((size_t)s * T + i) * D + h * 64 + dt * 16 + g * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      if (g == 0) lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
+    }
+  }
+}
+
+// dQ (query tiles stationary) + the row dots delta_i = dO_i . O_i, written for the dK/dV kernel
+template <int NB>
+__global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
+                                                           const half_t* __restrict__ datt, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, half_t* __restrict__ dqkv, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vs = Ks + NB * 4096;
+  half_t* Kt = Vs + NB * 4096;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  const half_t* dob = datt + (size_t)s * T * D + h * 64;
+  const half_t* ob = att + (size_t)s * T * D + h * 64;
+  for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
+    if (idx < NB * 64) atg_stage<NB>(base + D, ld, T, Ks, Kt, idx);
+    else atg_stage<NB>(base + 2 * D, ld, T, Vs, nullptr, idx - NB * 64);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+  for (int it = wave; it * 16 < T; it += 8) {
+    const int i = it * 16 + c16;
+    const bool live = i < T;
+    half8 qf[2], of[2];
+    float Di = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      qf[kd] = ld_frag_global(base + (size_t)i * ld + kd * 32 + g * 8, live);
+      of[kd] = ld_frag_global(dob + (size_t)i * D + kd * 32 + g * 8, live);
+      const half8 ov = ld_frag_global(ob + (size_t)i * D + kd * 32 + g * 8, live);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Di += (float)ov[e] * (float)of[kd][e];
+    }
+    Di += __shfl_xor(Di, 16);
+    Di += __shfl_xor(Di, 32);
+    const float Li = live ? lse[((size_t)s * heads + h) * T + i] : 0.f;
+    if (live && g == 0) delta[((size_t)s * heads + h) * T + i] = Di;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2 * NB; ++kb) {
+      if (kb * 32 < T) {
+        f32x4 st[2], dp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          st[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int jr = (2 * kb + u) * 16 + c16;
+#pragma unroll
+          for (int kd = 0; kd < 2; ++kd) {
+            st[u] = mfma_16x16x32_f16(at_frag(Ks, jr, kd * 4 + g), qf[kd], st[u]);
+            dp[u] = mfma_16x16x32_f16(at_frag(Vs, jr, kd * 4 + g), of[kd], dp[u]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = (2 * kb + u) * 16 + g * 4 + r < T ? __expf(st[u][r] * 0.125f - Li) : 0.f;
+            st[u][r] = p * (dp[u][r] - Di) * 0.125f;      // dS^T
+          }
+        }
+        const half8 df = pack8(st[0], st[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_16x16x32_f16(at_frag(Kt + (kb >> 1) * 4096, dt * 16 + c16, (kb & 1) * 4 + g), df, o[dt]);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_h4(dbase + (size_t)i * ld + dt * 16 + g * 4, o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    }
+  }
+}
+
+// dK, dV (key tiles stationary)
+template <int NB>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ datt,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            half_t* __restrict__ dqkv, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Qs = reinterpret_cast<half_t*>(smem);
+  half_t* Os = Qs + NB * 4096;
+  half_t* Qt = Os + NB * 4096;
+  half_t* Ot = Qt + NB * 4096;
+  float* Ls = reinterpret_cast<float*>(Ot + NB * 4096);
+  float* Ds = Ls + NB * 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  const half_t* dob = datt + (size_t)s * T * D + h * 64;
+  for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
+    if (idx < NB * 64) atg_stage<NB>(base, ld, T, Qs, Qt, idx);
+    else atg_stage<NB>(dob, D, T, Os, Ot, idx - NB * 64);
+  }
+  for (int r = threadIdx.x; r < NB * 64; r += 512) {
+    Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] : 0.f;
+    Ds[r] = r < T ? delta[((size_t)s * heads + h) * T + r] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+  for (int jt = wave; jt * 16 < T; jt += 8) {
+    const int j = jt * 16 + c16;
+    const bool live = j < T;
+    half8 kf[2], vf[2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      kf[kd] = ld_frag_global(base + (size_t)j * ld + D + kd * 32 + g * 8, live);
+      vf[kd] = ld_frag_global(base + (size_t)j * ld + 2 * D + kd * 32 + g * 8, live);
+    }
+    f32x4 ok[4], ov[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qb = 0; qb < 2 * NB; ++qb) {
+      if (qb * 32 < T) {
+        f32x4 sq[2], dq[2], pp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          sq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int t16 = (2 * qb + u) * 16;
+#pragma unroll
+          for (int kd = 0; kd < 2; ++kd) {
+            sq[u] = mfma_16x16x32_f16(at_frag(Qs, t16 + c16, kd * 4 + g), kf[kd], sq[u]);
+            dq[u] = mfma_16x16x32_f16(at_frag(Os, t16 + c16, kd * 4 + g), vf[kd], dq[u]);
+          }
+          const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + t16 + g * 4);
+          const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t16 + g * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = t16 + g * 4 + r < T ? __expf(sq[u][r] * 0.125f - L4[r]) : 0.f;
+            pp[u][r] = p;
+            sq[u][r] = p * (dq[u][r] - D4[r]) * 0.125f;     // dS
+          }
+        }
+        const half8 pf = pack8(pp[0], pp[1]), sf = pack8(sq[0], sq[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          ov[dt] = mfma_16x16x32_f16(at_frag(Ot + (qb >> 1) * 4096, dt * 16 + c16, (qb & 1) * 4 + g), pf, ov[dt]);
+          ok[dt] = mfma_16x16x32_f16(at_frag(Qt + (qb >> 1) * 4096, dt * 16 + c16, (qb & 1) * 4 + g), sf, ok[dt]);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[dt][0], ok[dt][1], ok[dt][2], ok[dt][3]);
+        store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[dt][0], ov[dt][1], ov[dt][2], ov[dt][3]);
+      }
+    }
+  }
+}
+
 }  // namespace aph

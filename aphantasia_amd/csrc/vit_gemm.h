@@ -529,10 +529,9 @@ inline int choose_splits(int M, int N, int K, const SplitKSpace* sp) {
   return splits;
 }
 
-template <class Epi>
+template <class C, class Epi>
 inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, int splits,
                                const SplitKSpace& sp, hipStream_t st) {
-  using C = GemmSmall;
   static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true>), C::SMEM), true);
   (void)once;
   const int tiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
@@ -566,7 +565,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {
     const int splits = choose_splits(M, N, K, sp);
-    if (splits > 1) launch_gemm_splitk(A, lda, Bt, ldb, M, N, K, epi, splits, *sp, st);
+    if (splits > 1) launch_gemm_splitk<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, splits, *sp, st);
     else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
   }
 }

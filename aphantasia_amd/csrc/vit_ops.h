@@ -1,5 +1,5 @@
 // Non-GEMM kernels of the CLIP ViT forward / input-gradient backward:
-// LayerNorm (fp32 statistics), small-sequence multi-head attention (T = 50 / 197, head dim 64),
+// LayerNorm (fp32 statistics) -- multi-head attention lives in vit_attn.h --,
 // class-token / positional embedding, ln_post + projection head.
 // Follows openai/CLIP clip/model.py VisionTransformer / ResidualAttentionBlock (see
 // oracle/clip_vit_ref.py for the restatement these kernels are tested against).
@@ -126,165 +126,6 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
       half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
       *reinterpret_cast<half4*>(out16 + orow * D + d) = h;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// Attention, one workgroup per (image, head); thread i owns query row i.  K/V (and Q/dO in the
-// backward) are staged in LDS as f16 and read as wave-wide broadcasts; all arithmetic fp32.
-// qkv: [M, 3D] f16 (q | k | v, head h at columns h*64..), att: [M, D] f16, lse: [S*heads*T] f32.
-// ---------------------------------------------------------------------------------
-struct alignas(16) H8 { half2 p[4]; };   // 8 halfs = one 16-byte LDS / global access
-
-__device__ __forceinline__ void load_row64h(const half_t* __restrict__ p, H8 r[8]) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) r[c] = *reinterpret_cast<const H8*>(p + c * 8);
-}
-// fp16 x fp16 dot with fp32 accumulation (v_dot2_f32_f16)
-__device__ __forceinline__ float dot_hh(const H8 a[8], const half_t* __restrict__ b) {
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const H8 t = *reinterpret_cast<const H8*>(b + c * 8);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = dot2_f16(a[c].p[u], t.p[u], acc);
-  }
-  return acc;
-}
-__device__ __forceinline__ void axpy_row64(float acc[64], float w, const half_t* __restrict__ b) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const H8 t = *reinterpret_cast<const H8*>(b + c * 8);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[c * 8 + 2 * u] += w * (float)t.p[u][0];
-      acc[c * 8 + 2 * u + 1] += w * (float)t.p[u][1];
-    }
-  }
-}
-__device__ __forceinline__ void store_row64(half_t* __restrict__ dst, const float v[64], float scale) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    half8 hv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) hv[j] = (half_t)(v[c * 8 + j] * scale);
-    *reinterpret_cast<half8*>(dst + c * 8) = hv;
-  }
-}
-__device__ __forceinline__ void stage_rows(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld, int T) {
-  // T rows x 64 halfs, 16-byte chunks
-  for (int q = threadIdx.x; q < T * 8; q += blockDim.x) {
-    const int r = q >> 3, c = q & 7;
-    *reinterpret_cast<H8*>(dst + r * 64 + c * 8) = *reinterpret_cast<const H8*>(src + (size_t)r * ld + c * 8);
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att, float* __restrict__ lse, int T, int heads) {
-  APH_DYN_SMEM(smem);
-  half_t* Ks = reinterpret_cast<half_t*>(smem);
-  half_t* Vs = Ks + T * 64;
-  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
-  const int D = heads * kHeadDim, ld = 3 * D;
-  const half_t* base = qkv + (size_t)s * T * ld + h * kHeadDim;
-  stage_rows(Ks, base + D, ld, T);
-  stage_rows(Vs, base + 2 * D, ld, T);
-  __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= T) return;
-  H8 q[8];
-  float o[64];
-  load_row64h(base + (size_t)i * ld, q);
-#pragma unroll
-  for (int d = 0; d < 64; ++d) o[d] = 0.f;
-  float mx = -1e30f, l = 0.f;
-  for (int j0 = 0; j0 < T; j0 += 8) {
-    float sc[8];
-    float cm = mx;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      sc[u] = (j0 + u < T) ? dot_hh(q, Ks + (j0 + u) * 64) * 0.125f : -1e30f;   // head_dim ** -0.5
-      cm = fmaxf(cm, sc[u]);
-    }
-    const float f = __expf(mx - cm);
-    l *= f;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] *= f;
-    mx = cm;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (j0 + u < T) {
-        const float p = __expf(sc[u] - mx);
-        l += p;
-        axpy_row64(o, p, Vs + (j0 + u) * 64);
-      }
-    }
-  }
-  store_row64(att + ((size_t)s * T + i) * D + h * kHeadDim, o, 1.0f / l);
-  lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
-}
-
-// backward: dO = datt [M,D] f16 -> dqkv [M,3D] f16.  P is recomputed from q, k and the saved lse.
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att, const half_t* __restrict__ datt,
-                                const float* __restrict__ lse, half_t* __restrict__ dqkv, int T, int heads) {
-  APH_DYN_SMEM(smem);
-  half_t* Qs = reinterpret_cast<half_t*>(smem);
-  half_t* Ks = Qs + T * 64;
-  half_t* Vs = Ks + T * 64;
-  half_t* Os = Vs + T * 64;               // dO
-  float* Ls = reinterpret_cast<float*>(Os + T * 64);
-  float* Ds = Ls + T;
-  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
-  const int D = heads * kHeadDim, ld = 3 * D;
-  const half_t* base = qkv + (size_t)s * T * ld + h * kHeadDim;
-  const half_t* dob = datt + (size_t)s * T * D + h * kHeadDim;
-  const half_t* ob = att + (size_t)s * T * D + h * kHeadDim;
-  stage_rows(Qs, base, ld, T);
-  stage_rows(Ks, base + D, ld, T);
-  stage_rows(Vs, base + 2 * D, ld, T);
-  stage_rows(Os, dob, D, T);
-  const int i = threadIdx.x;
-  const bool live = i < T;
-  if (live) {
-    H8 o[8];
-    load_row64h(ob + (size_t)i * D, o);
-    Ds[i] = dot_hh(o, dob + (size_t)i * D);          // D_i = dO_i . O_i
-    Ls[i] = lse[((size_t)s * heads + h) * T + i];
-  }
-  __syncthreads();
-  half_t* dbase = dqkv + (size_t)s * T * ld + h * kHeadDim;
-  if (live) {
-    // phase 1 (query rows): dq_i = scale * sum_j p_ij (dP_ij - D_i) k_j
-    H8 q[8], go[8];
-    float dq[64];
-    load_row64h(Qs + i * 64, q);
-    load_row64h(Os + i * 64, go);
-#pragma unroll
-    for (int d = 0; d < 64; ++d) dq[d] = 0.f;
-    const float Li = Ls[i], Di = Ds[i];
-    for (int j = 0; j < T; ++j) {
-      const float p = __expf(dot_hh(q, Ks + j * 64) * 0.125f - Li);
-      const float dp = dot_hh(go, Vs + j * 64);
-      axpy_row64(dq, p * (dp - Di) * 0.125f, Ks + j * 64);
-    }
-    store_row64(dbase + (size_t)i * ld, dq, 1.0f);
-  }
-  if (live) {
-    // phase 2 (key rows, thread j = i): dv_j = sum_i p_ij dO_i ; dk_j = scale * sum_i dS_ij q_i
-    const int j = i;
-    H8 k[8], v[8];
-    float dk[64], dv[64];
-    load_row64h(Ks + j * 64, k);
-    load_row64h(Vs + j * 64, v);
-#pragma unroll
-    for (int d = 0; d < 64; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    for (int r = 0; r < T; ++r) {
-      const float p = __expf(dot_hh(k, Qs + r * 64) * 0.125f - Ls[r]);
-      const float dp = dot_hh(v, Os + r * 64);
-      axpy_row64(dv, p, Os + r * 64);
-      axpy_row64(dk, p * (dp - Ds[r]) * 0.125f, Qs + r * 64);
-    }
-    store_row64(dbase + (size_t)j * ld + D, dk, 1.0f);
-    store_row64(dbase + (size_t)j * ld + 2 * D, dv, 1.0f);
   }
 }
 

@@ -83,3 +83,10 @@ def test_vit_50_tokens(emu):
     # T = 50 like ViT-B/32: four 16-row attention tiles with a ragged last one
     cfg = dict(input_resolution=112, patch_size=16, width=256, layers=1, heads=4, output_dim=128)
     K.check_vit(emu, 'cpu', cfg, S=2)
+
+
+@pytest.mark.parametrize('res', [144, 224])
+def test_vit_long_sequences(emu, res):
+    # T = 82 (two 64-token blocks) and T = 197 like ViT-B/16 (four blocks, ragged last tile): blocked MFMA attention
+    cfg = dict(input_resolution=res, patch_size=16, width=256, layers=1, heads=4, output_dim=128)
+    K.check_vit(emu, 'cpu', cfg, S=1)

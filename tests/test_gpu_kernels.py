@@ -95,6 +95,17 @@ def test_vit_tiny():
     K.check_vit(None, DEV)
 
 
+@pytest.mark.parametrize('res', [80, 144, 192, 224, 256])
+def test_vit_sequence_lengths(res):
+    # T = 26, 82, 145, 197, 257->rejected?  (one-tile MFMA attention, then the blocked kernels with 2, 3, 4 blocks)
+    cfg = dict(input_resolution=res, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
+    if (res // 16) ** 2 + 1 > 256:
+        with pytest.raises(RuntimeError):
+            K.check_vit(None, DEV, cfg, S=2)
+        return
+    K.check_vit(None, DEV, cfg, S=2)
+
+
 @pytest.mark.parametrize('name', ['ViT-B/32', 'ViT-B/16'])
 def test_vit_base(name):
     from aphantasia_amd.weights import visual_config

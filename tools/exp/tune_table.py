@@ -4,12 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from aphantasia_amd import _ffi
 from aphantasia_amd.ops import ptr, _stream
 L = _ffi.lib()
-for M in (1200, 2400, 4750, 9500):
+for M in (1200, 2400):
     for (N, K) in ((768, 768), (2304, 768), (3072, 768), (768, 2304), (768, 3072)):
         A = torch.randn(M, K, device='cuda').half(); B = torch.randn(N, K, device='cuda').half(); C = torch.empty(M, N, device='cuda')
         line = 'M %5d N %5d K %5d:' % (M, N, K)
         best = None
-        for cfg in (0, 1, 5, 20, 21, 2):
+        for cfg in (0, 1, 10, 22, 24):
             s = torch.cuda.Stream()
             with torch.cuda.stream(s):
                 st = _stream(A)
