@@ -378,6 +378,68 @@ __global__ void norm_bwd_kernel(const float* __restrict__ dn, const float* __res
     draw[i] = A * dn[i] + Bc * (raw[i] - mu);
 }
 
+// ---------------------------------------------------------------------------------
+// illustrip's RGB priors (illustrip.py:438-440, `--gen RGB`):
+//     loss += mean_c |mean_hw(rgb_c) - t_mean|  +  mean_c |std_hw(rgb_c) - t_std|        (unbiased std)
+// Per-channel (sum, sumsq) in fp64 block partials, then value and gradient in one elementwise pass:
+//     d/d rgb_c[p] = [sign(m_c - t_mean) / HW  +  sign(s_c - t_std) (rgb_c[p] - m_c) / ((HW - 1) s_c)] / 3
+// ---------------------------------------------------------------------------------
+constexpr int kPriorBlocks = 128;
+
+__global__ void rgb_prior_partial_kernel(const float* __restrict__ rgb, size_t HW, double* __restrict__ partials) {
+  __shared__ double red[16];
+  const float* x = rgb + (size_t)blockIdx.y * HW;
+  double s1 = 0.0, s2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    s1 += v; s2 += (double)v * v;
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    double* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = s1; o[1] = s2;
+  }
+}
+
+__device__ __forceinline__ void prior_channel_stats(const double* __restrict__ partials, int nb, int c, double n, double& mean, double& sd) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nb; ++i) { s1 += partials[((size_t)c * nb + i) * 2]; s2 += partials[((size_t)c * nb + i) * 2 + 1]; }
+  mean = s1 / n;
+  double var = (s2 - s1 * mean) / (n - 1.0);
+  sd = sqrt(var > 0 ? var : 0);
+}
+
+__global__ void rgb_prior_apply_kernel(const float* __restrict__ rgb, size_t HW, const double* __restrict__ partials, int nb,
+                                       float t_mean, float t_std, float weight, float* __restrict__ loss, float* __restrict__ grgb) {
+  __shared__ float ab[3];
+  const int c = blockIdx.y;
+  const double n = (double)HW;
+  if (threadIdx.x == 0) {
+    double m, sd;
+    prior_channel_stats(partials, nb, c, n, m, sd);
+    const double sm = m > t_mean ? 1.0 : (m < t_mean ? -1.0 : 0.0), ss = sd > t_std ? 1.0 : (sd < t_std ? -1.0 : 0.0);
+    ab[0] = (float)(weight * sm / (3.0 * n));
+    ab[1] = sd > 0 ? (float)(weight * ss / (3.0 * (n - 1.0) * sd)) : 0.f;
+    ab[2] = (float)m;
+    if (loss && blockIdx.x == 0 && c == 0) {          // one thread adds the value of all three channels (fixed order)
+      double v = 0.0;
+      for (int cc = 0; cc < 3; ++cc) {
+        double m2, s2;
+        prior_channel_stats(partials, nb, cc, n, m2, s2);
+        v += fabs(m2 - t_mean) / 3.0 + fabs(s2 - t_std) / 3.0;
+      }
+      loss[0] += (float)(weight * v);
+    }
+  }
+  __syncthreads();
+  if (!grgb) return;
+  const float a = ab[0], b = ab[1], mu = ab[2];
+  const float* x = rgb + (size_t)c * HW;
+  float* g = grgb + (size_t)c * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) g[i] += a + b * (x[i] - mu);
+}
+
 }  // namespace aph
 
 // =====================================================================================
@@ -559,6 +621,23 @@ int aph_synth_set_stats(aph_synth_plan* p, const float* in2, void* stream_) {
   if (hipMemcpyAsync(p->stats, in2, 2 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_) != hipSuccess)
     return aph_fail(APH_ERR_HIP, "aph_synth_set_stats: copy failed");
   return APH_OK;
+  APH_CATCH
+}
+
+// illustrip.py:438-440 RGB priors on rgb [3,H,W]: adds weight * value to *d_loss (nullable) and weight * gradient to
+// d_rgb_grad (nullable, accumulated in place).  d_ws: >= aph_rgb_priors_ws_bytes() bytes of device scratch.
+size_t aph_rgb_priors_ws_bytes(void) { return sizeof(double) * 3 * kPriorBlocks * 2; }
+
+int aph_rgb_priors(const float* d_rgb, int H, int W, float t_mean, float t_std, float weight, void* d_ws, float* d_loss,
+                   float* d_rgb_grad, void* stream_) {
+  APH_TRY
+  if (!d_rgb || !d_ws || H < 1 || W < 1 || (size_t)H * W < 2) return aph_fail(APH_ERR_ARG, "aph_rgb_priors: bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const size_t HW = (size_t)H * W;
+  APH_LAUNCH(rgb_prior_partial_kernel, dim3(kPriorBlocks, 3), dim3(256), 0, st, d_rgb, HW, (double*)d_ws);
+  APH_LAUNCH(rgb_prior_apply_kernel, dim3(kPriorBlocks, 3), dim3(256), 0, st, d_rgb, HW, (const double*)d_ws, kPriorBlocks, t_mean, t_std,
+             weight, d_loss, d_rgb_grad);
+  return aph_check_launch("aph_rgb_priors");
   APH_CATCH
 }
 

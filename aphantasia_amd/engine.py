@@ -34,7 +34,8 @@ def shard_range(S, rank, world):
 class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
-                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True):
+                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
+                 rgb_priors=None, fixcontrast=False):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -57,6 +58,8 @@ class Engine:
         self.sim = sim
         self.rng_mode = rng
         self.use_graph, self._graphs, self._calls = use_graph, None, 0
+        self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
+        self.fixcontrast = bool(fixcontrast)
         self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
         self.cc = colcorr_t(colors).flatten().tolist()
@@ -97,6 +100,7 @@ class Engine:
         self.grgb = torch.empty(3, h, w, **f32)
         self.grad = torch.empty_like(params)
         self.loss = torch.zeros(1, **f32)
+        self.prior_ws = torch.empty(int(self.lib.cdll.aph_rgb_priors_ws_bytes()) // 8, device=self.dev, dtype=torch.float64)
         self.ws = torch.empty(Sl * (len(targets) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
@@ -141,12 +145,14 @@ class Engine:
                    _ffi.floats(self.cc), int(self.decorrelate), ops.ptr(self.raw), ops.ptr(self.rgb), st)
         else:
             self.spatial = self.dwt.forward(self.params) if self.kind == 'dwt' else self.params
-            L.call('aph_synth_spatial_fwd', self.plan.handle, ops.ptr(self.spatial), float(contrast), 0.0, _ffi.floats(self.cc),
+            fixed_div = 3.3 if (self.fixcontrast and self.kind == 'pixel') else 0.0         # image.py:114-116
+            L.call('aph_synth_spatial_fwd', self.plan.handle, ops.ptr(self.spatial), float(contrast), fixed_div, _ffi.floats(self.cc),
                    int(self.decorrelate), ops.ptr(self.rgb), st)
         return self.rgb
 
     def _enqueue_grad(self, shift):
         """forward + backward up to the parameter gradient: C-ABI calls only (capturable into a hipGraph)"""
+        fixed_div = 3.3 if (self.fixcontrast and self.kind == 'pixel') else 0.0
         L, st = self.lib, ops._stream(self.params)
         Sl = self.S_loc
         self.synthesize(1.0, shift)
@@ -164,6 +170,9 @@ class Engine:
         else:
             self.grgb.zero_()
             self.loss.zero_()
+        if self.rgb_priors is not None and self.rank == 0:       # illustrip.py:438-440; replicated term -> one rank adds it
+            L.call('aph_rgb_priors', ops.ptr(self.rgb), self.h, self.w, float(self.rgb_priors[0]), float(self.rgb_priors[1]), 1.0,
+                   ops.ptr(self.prior_ws), ops.ptr(self.loss), ops.ptr(self.grgb), st)
         if self.kind == 'fft':
             L.call('aph_synth_fft_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.raw), ops.ptr(self.scale),
                    1.0, cc, int(self.decorrelate), ops.ptr(self.grad), st)
@@ -172,7 +181,7 @@ class Engine:
                    int(self.decorrelate), ops.ptr(self.raw), st)            # d raw (reuses the raw buffer)
             self.dwt.backward(self.raw, self.grad)
         else:
-            L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, 0.0, cc,
+            L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, fixed_div, cc,
                    int(self.decorrelate), ops.ptr(self.grad), st)
 
     def _enqueue_adam(self):

@@ -59,6 +59,13 @@ int aph_synth_stats(aph_synth_plan* plan, float* d_out2, void* stream);
 /* restore them (d_in2 device, 2 floats) before an adjoint whose forward was followed by other forwards */
 int aph_synth_set_stats(aph_synth_plan* plan, const float* d_in2, void* stream);
 
+/* illustrip.py:438-440 (`--gen RGB` priors): mean_c |mean_hw(rgb_c) - t_mean| + mean_c |std_hw(rgb_c) - t_std| (unbiased
+ * std) over d_rgb [3,H,W].  Adds weight * value to *d_loss (nullable) and weight * gradient into d_rgb_grad (nullable,
+ * accumulated).  d_ws: device scratch of aph_rgb_priors_ws_bytes() bytes. */
+size_t aph_rgb_priors_ws_bytes(void);
+int aph_rgb_priors(const float* d_rgb, int H, int W, float t_mean, float t_std, float weight, void* d_ws, float* d_loss,
+                   float* d_rgb_grad, void* stream);
+
 /* ---- wavelet parameteriser: aphantasia/image.py:33-80 (dwt_image) over pytorch_wavelets.DWTInverse ------- */
 /* One synthesis level (lowlevel.SFB2D, mode 'symmetric').  d_ll [C,ll_h,ll_w] running low band (ll_h in {h,h+1}:
  * the extra row/col DWTInverse.forward drops is ignored), d_highs [C,3,h,w] = (LH,HL,HH) of this level,

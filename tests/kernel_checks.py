@@ -240,3 +240,23 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2):
     berr = (gx.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
     assert berr < bwd_tol, berr
     return ferr, berr
+
+
+def check_rgb_priors(lib, dev):
+    """aph_rgb_priors vs torch autograd on the expression of illustrip.py:439-440"""
+    from aphantasia_amd import _ffi
+    L = lib if lib is not None else _ffi.lib()
+    g = torch.Generator().manual_seed(4)
+    for (h, w) in ((37, 53), (64, 200)):
+        x = (torch.rand(1, 3, h, w, generator=g) * torch.tensor([0.3, 0.9, 0.6]).view(1, 3, 1, 1)).requires_grad_(True)
+        want = abs(x.mean((2, 3)) - 0.45).mean() + abs(x.std((2, 3)) - 0.17).mean()
+        want.backward()
+        rgb = x.detach().reshape(3, h, w).to(dev).contiguous()
+        base = 1e-4 * torch.randn(3, h, w, generator=g)
+        grad = base.clone().to(dev)
+        loss = torch.full((1,), 0.25, device=dev)
+        ws = torch.empty(int(L.cdll.aph_rgb_priors_ws_bytes()) // 8, dtype=torch.float64, device=dev)
+        L.call('aph_rgb_priors', ops.ptr(rgb), h, w, 0.45, 0.17, 2.0, ops.ptr(ws), ops.ptr(loss), ops.ptr(grad), ops._stream(rgb))
+        assert abs(loss.item() - 0.25 - 2.0 * want.item()) < 1e-6
+        err = (grad.cpu() - base - 2.0 * x.grad.reshape(3, h, w)).abs().max().item()
+        assert err < 1e-4 * (2.0 * x.grad.abs().max().item() + 1e-4), err

@@ -90,3 +90,7 @@ def test_vit_long_sequences(emu, res):
     # T = 82 (two 64-token blocks) and T = 197 like ViT-B/16 (four blocks, ragged last tile): blocked MFMA attention
     cfg = dict(input_resolution=res, patch_size=16, width=256, layers=1, heads=4, output_dim=128)
     K.check_vit(emu, 'cpu', cfg, S=1)
+
+
+def test_rgb_priors(emu):
+    K.check_rgb_priors(emu, 'cpu')

@@ -111,3 +111,7 @@ def test_vit_base(name):
     from aphantasia_amd.weights import visual_config
     ferr, berr = K.check_vit(None, DEV, visual_config(name), S=3, fwd_tol=5e-3, bwd_tol=3e-2)
     print('%s fwd rel err %.2e  bwd rel err %.2e' % (name, ferr, berr))
+
+
+def test_rgb_priors():
+    K.check_rgb_priors(None, DEV)

@@ -192,3 +192,31 @@ def test_dwt_and_pixel_engines_vs_autograd_api(model):
         l2 = float(eng.step())
         assert abs(l2 - float(loss)) < 1e-5, kind
         assert (eng.grad.reshape(-1) - grads).abs().max().item() < 1e-4 * grads.abs().max().item() + 1e-9, kind
+
+
+def test_illustrip_rgb_step_priors_and_fixcontrast(model):
+    """illustrip.py:425-440 inner step with `--gen RGB`: pixel_image(fixcontrast) + the brightness / contrast priors, fused
+    engine (aph_rgb_priors) vs the same arithmetic written with torch ops on top of the drop-in autograd API"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd.image import pixel_image, to_valid_rgb
+    from aphantasia_amd.utils import slice_imgs, sim_func
+    from aphantasia_amd import transforms
+    h, w, S = 256, 320, 4
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    for fix in (False, True):
+        seed_all(0)
+        params, image_f, _ = pixel_image([1, 3, h, w], sd=1.0)
+        rgb_f = to_valid_rgb(image_f, colors=1.8)
+        seed_all(5)
+        img_out = rgb_f(fixcontrast=fix)
+        cuts = slice_imgs([img_out], S, 224, transforms.normalize(), 'uniform', 0.4)[0]
+        loss = abs(img_out.mean((2, 3)) - 0.45).mean() + abs(img_out.std((2, 3)) - 0.17).mean()
+        loss = loss - sim_func(target.to(DEV), model.encode_image(cuts), 'mix')
+        loss.backward()
+        eng = Engine(params[0].detach().clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(), param_kind='pixel',
+                     rng='reference', rgb_priors=True, fixcontrast=fix)
+        seed_all(5)
+        l2 = float(eng.step())
+        assert abs(l2 - float(loss)) < 2e-5, (fix, l2, float(loss))
+        g = params[0].grad.reshape(-1)
+        assert (eng.grad.reshape(-1) - g).abs().max().item() < 1e-4 * g.abs().max().item() + 1e-9, fix
