@@ -120,10 +120,55 @@ class FFTImage:
         return _SynthFFT.apply(self.params, self, self._shift(shift), float(contrast), cc, decorrelate, True)
 
 
+# ---- resume-from-image helpers (host, one-off; image.py:179-220) -------------------------------------------------
+_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def inv_sigmoid(x):
+    """image.py:179-183"""
+    eps = 1.e-12
+    x = torch.clamp(x.double(), eps, 1 - eps)
+    return torch.log(x / (1 - x)).float()
+
+
+def un_rgb(image, colors=1.):
+    """image.py:185-197: inverse of to_valid_rgb's colour mixing, applied to the CLIP-normalised image (the reference's
+    'experimental' choice; inv_sigmoid is commented out upstream).  numpy uint8 HWC or a float NCHW tensor in."""
+    cc_inv = torch.linalg.inv(colcorr_t(colors))
+    if not isinstance(image, torch.Tensor):
+        image = torch.Tensor(np.array(image)).permute(2, 0, 1).unsqueeze(0) / 255.
+    mean = torch.tensor(_CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(_CLIP_STD).view(1, 3, 1, 1)
+    image = (image.cpu().float() - mean) / std                      # transforms.normalize()
+    return torch.einsum('nchw,cd->ndhw', image, cc_inv)
+
+
+def un_spectrum(spectrum, decay_power):
+    """image.py:199-206 (note the 1/max(w,h) floor here vs 4/max(w,h) in fft_image)"""
+    h = spectrum.shape[2]
+    w = (spectrum.shape[3] - 1) * 2
+    freqs = rfft2d_freqs(h, w)
+    scale = 1.0 / np.maximum(freqs, 1.0 / max(w, h)) ** decay_power
+    scale *= np.sqrt(w * h)
+    scale = torch.tensor(scale).float()[None, None, ..., None]
+    return spectrum / scale
+
+
+def img2fft(img_in, decay=1., colors=1.):
+    """image.py:208-220 -> spectrum [1,3,h,w//2+1,2] (host tensor)"""
+    image_t = un_rgb(img_in, colors=colors)
+    h, w = image_t.shape[2], image_t.shape[3]
+    with torch.no_grad():
+        spectrum = torch.view_as_real(torch.fft.rfftn(image_t, s=(h, w), dim=[2, 3], norm='ortho'))
+        spectrum = un_spectrum(spectrum, decay_power=decay)
+        spectrum = spectrum * 500000.                               # [sic], image.py:219
+    return spectrum
+
+
 def resume_fft(resume=None, shape=None, decay=None, colors=1.6, sd=0.01):
     """image.py:130-150.  Random init draws on torch's CPU generator exactly as the reference does
-    (0.01*randn on the host, then moved to the device).  `.pt` snapshots are supported; resuming
-    from an image file (img2fft) is not part of the accelerated path yet."""
+    (0.01*randn on the host, then moved to the device).  `.pt` snapshots and image files (img2fft) resume as upstream."""
     size = None
     if resume is None:
         params_shape = [*shape[:3], shape[3] // 2 + 1, 2]
@@ -133,10 +178,14 @@ def resume_fft(resume=None, shape=None, decay=None, colors=1.6, sd=0.01):
             print(' Snapshot not found:', resume)
             exit()
         if os.path.splitext(resume)[1].lower()[1:] in ['jpg', 'png', 'tif', 'bmp']:
-            raise NotImplementedError('resuming the FFT parameters from an image file (img2fft) is not implemented')
-        params = torch.load(resume)
-        if isinstance(params, list):
-            params = params[0]
+            from .utils import img_read
+            img_in = img_read(resume)
+            params = img2fft(img_in, decay, colors)
+            size = img_in.shape[:2]
+        else:
+            params = torch.load(resume)
+            if isinstance(params, list):
+                params = params[0]
         params = params.detach().float() * sd
     else:
         if isinstance(resume, list):
@@ -203,7 +252,14 @@ def pixel_image(shape, resume=None, sd=1., *noargs, **nokwargs):
     if resume is None:
         image_t = torch.randn(*shape) * sd
     elif isinstance(resume, str):
-        raise NotImplementedError('resuming pixel_image from an image file is not implemented')
+        if not os.path.isfile(resume):
+            print(' Image not found:', resume)
+            exit()
+        from .utils import img_read
+        img_in = img_read(resume)
+        image_t = 3.3 * un_rgb(img_in, colors=2.)
+        size = img_in.shape[:2]
+        print(resume, size)
     else:
         if isinstance(resume, list):
             resume = resume[0]

@@ -95,6 +95,22 @@ def gold_run(ref, name, steps=6):
                         losses=np.array(losses), params_final=params[0].detach().numpy(), final=final)
 
 
+def gold_resume(ref, name):
+    """resume-from-image helpers of the reference (image.py:179-220): inv_sigmoid, un_rgb, un_spectrum, img2fft, and
+    pixel_image's `3.3 * un_rgb(img, colors=2.)` init"""
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (30, 44, 3), generator=g).numpy().astype(np.uint8)
+    spec = torch.randn(1, 3, 30, 23, 2, generator=g)
+    x = torch.rand(1, 3, 5, 7, generator=g)
+    out = dict(img=img, spec=spec.numpy(), x=x.numpy(),
+               inv_sigmoid=ref.image.inv_sigmoid(x).numpy(),
+               un_rgb_c15=ref.image.un_rgb(img, colors=1.5).numpy(),
+               un_rgb_tensor=ref.image.un_rgb(x, colors=1.0).numpy(),
+               un_spectrum=ref.image.un_spectrum(spec.clone(), 1.5).numpy(),
+               img2fft=ref.image.img2fft(img, 1.5, 1.5).numpy())
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = shim.load_reference()
@@ -103,6 +119,7 @@ def main():
     gold_slice(ref, 'slice_48x80.npz')
     gold_sim(ref, 'sim.npz')
     gold_run(ref, 'run_40x56.npz')
+    gold_resume(ref, 'resume_img.npz')
     print('goldens written to', OUT)
 
 

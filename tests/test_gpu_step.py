@@ -1,3 +1,4 @@
+import os
 """GPU (MI355X): the whole optimisation step through the product library -- drop-in autograd API,
 fused engine, loss-curve parity with the oracle, and size-independent properties at BASELINE's sizes."""
 import warnings
@@ -220,3 +221,24 @@ def test_illustrip_rgb_step_priors_and_fixcontrast(model):
         assert abs(l2 - float(loss)) < 2e-5, (fix, l2, float(loss))
         g = params[0].grad.reshape(-1)
         assert (eng.grad.reshape(-1) - g).abs().max().item() < 1e-4 * g.abs().max().item() + 1e-9, fix
+
+
+def test_cli_resume_from_image_and_pt(tmp_path):
+    """clip_fft.py --resume <image> (img2fft init, size from the image, align -> overscan) then --resume <.pt snapshot>"""
+    import numpy as np
+    from PIL import Image
+    import clip_fft
+    rng = np.random.default_rng(0)
+    img = (rng.random((96, 128, 3)) * 255).astype(np.uint8)
+    jpg = os.path.join(tmp_path, 'start.png')
+    Image.fromarray(img).save(jpg)
+    out = os.path.join(tmp_path, 'out')
+    clip_fft.main(['-t', 'cat', '-nv', '--seed', '0', '--steps', '3', '--samples', '12', '--resume', jpg, '--out_dir', out, '--save_pt'])
+    pts = [f for f in os.listdir(out) if f.endswith('.pt')]
+    assert len(pts) == 1
+    snap = torch.load(os.path.join(out, pts[0]))
+    assert isinstance(snap, list) and tuple(snap[0].shape) == (1, 3, 96, 65, 2)          # clip_fft.py:315 list-of-tensors format
+    frames = [f for f in os.listdir(os.path.join(out, os.path.splitext(pts[0])[0])) if f.endswith('.jpg')]
+    assert len(frames) == 3
+    clip_fft.main(['-t', 'cat', '-nv', '--seed', '0', '--steps', '2', '--samples', '12', '--size', '128-96', '--resume', os.path.join(out, pts[0]),
+                   '--out_dir', os.path.join(tmp_path, 'out2'), '--no_save'])
