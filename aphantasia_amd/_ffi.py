@@ -38,6 +38,7 @@ _PROTOTYPES = {
     'aph_synth_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
     'aph_synth_set_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
     'aph_rgb_priors_ws_bytes': (c_size_t, []),
+    'aph_rgb_sharp': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_rgb_priors': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_idwt_level_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'aph_idwt_level_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),

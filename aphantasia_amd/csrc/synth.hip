@@ -440,6 +440,50 @@ __global__ void rgb_prior_apply_kernel(const float* __restrict__ rgb, size_t HW,
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) g[i] += a + b * (x[i] - mu);
 }
 
+// ---------------------------------------------------------------------------------
+// --sharp term (clip_fft.py:269-270): derivat(img, 'naiv') = 0.5 (mean |d/dx| + mean |d/dy|)  (utils.py:265-268)
+// over rgb [3,H,W]; value and gradient (sub-gradient 0 at ties, as torch.abs) in two passes.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void rgb_sharp_partial_kernel(const float* __restrict__ rgb, int H, int W, double* __restrict__ partials) {
+  __shared__ double red[16];
+  const size_t n = (size_t)3 * H * W;
+  double sx = 0.0, sy = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float v = rgb[i];
+    if (x + 1 < W) sx += fabsf(rgb[i + 1] - v);
+    if (y + 1 < H) sy += fabsf(rgb[i + W] - v);
+  }
+  sx = block_sum(sx, red);
+  sy = block_sum(sy, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sx; partials[2 * blockIdx.x + 1] = sy; }
+}
+
+__global__ void rgb_sharp_apply_kernel(const float* __restrict__ rgb, int H, int W, const double* __restrict__ partials, int nb,
+                                       float weight, float* __restrict__ loss, float* __restrict__ grgb) {
+  const double nx = 3.0 * H * (W - 1), ny = 3.0 * (H - 1) * W;
+  if (loss && blockIdx.x == 0 && threadIdx.x == 0) {
+    double sx = 0.0, sy = 0.0;
+    for (int i = 0; i < nb; ++i) { sx += partials[2 * i]; sy += partials[2 * i + 1]; }
+    loss[0] += (float)(weight * 0.5 * (sx / nx + sy / ny));
+  }
+  if (!grgb) return;
+  const float kx = (float)(0.5 * weight / nx), ky = (float)(0.5 * weight / ny);
+  const size_t n = (size_t)3 * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float v = rgb[i];
+    float gx = 0.f, gy = 0.f;
+    if (x > 0) gx += sgnf(v - rgb[i - 1]);
+    if (x + 1 < W) gx -= sgnf(rgb[i + 1] - v);
+    if (y > 0) gy += sgnf(v - rgb[i - W]);
+    if (y + 1 < H) gy -= sgnf(rgb[i + W] - v);
+    grgb[i] += kx * gx + ky * gy;
+  }
+}
+
 }  // namespace aph
 
 // =====================================================================================
@@ -638,6 +682,18 @@ int aph_rgb_priors(const float* d_rgb, int H, int W, float t_mean, float t_std, 
   APH_LAUNCH(rgb_prior_apply_kernel, dim3(kPriorBlocks, 3), dim3(256), 0, st, d_rgb, HW, (const double*)d_ws, kPriorBlocks, t_mean, t_std,
              weight, d_loss, d_rgb_grad);
   return aph_check_launch("aph_rgb_priors");
+  APH_CATCH
+}
+
+// clip_fft.py:269-270: adds weight * derivat(rgb, 'naiv') to *d_loss (nullable) and its gradient into d_rgb_grad (nullable,
+// accumulated); pass weight = -a.sharp.  d_ws as for aph_rgb_priors.
+int aph_rgb_sharp(const float* d_rgb, int H, int W, float weight, void* d_ws, float* d_loss, float* d_rgb_grad, void* stream_) {
+  APH_TRY
+  if (!d_rgb || !d_ws || H < 2 || W < 2) return aph_fail(APH_ERR_ARG, "aph_rgb_sharp: bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  APH_LAUNCH(rgb_sharp_partial_kernel, dim3(kPriorBlocks), dim3(256), 0, st, d_rgb, H, W, (double*)d_ws);
+  APH_LAUNCH(rgb_sharp_apply_kernel, dim3(1024), dim3(256), 0, st, d_rgb, H, W, (const double*)d_ws, kPriorBlocks, weight, d_loss, d_rgb_grad);
+  return aph_check_launch("aph_rgb_sharp");
   APH_CATCH
 }
 

@@ -35,7 +35,7 @@ class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False):
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -60,6 +60,7 @@ class Engine:
         self.use_graph, self._graphs, self._calls = use_graph, None, 0
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
+        self.sharp, self.expand = float(sharp), float(expand)       # clip_fft.py:269-270, :276-280
         self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
         self.cc = colcorr_t(colors).flatten().tolist()
@@ -124,11 +125,29 @@ class Engine:
         for t, _ in per:
             if t.shape[0] != self.S:
                 raise ValueError('per-cut target has %d rows, expected %d' % (t.shape[0], self.S))
+        if self.expand > 0:          # slot of the previous step's encodings (clip_fft.py:276-280); inactive (coef 0) until one exists
+            per = per + [(torch.ones(self.S, bro[0][0].shape[-1] if bro else per[0][0].shape[-1]), 0.0)]
         self.n_broadcast = len(bro)
         self.targets = torch.cat([t.reshape(-1, t.shape[-1]).float().to(self.dev) for t, _ in bro + per], 0).contiguous()
         self.coef = [float(c) for _, c in bro + per]
         self.dcoef = torch.tensor(self.coef, dtype=torch.float32, device=self.dev)
         self.hcoef = _ffi.floats(self.coef)
+
+    def set_prev_enc(self, enc_rows=None):
+        """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
+        target of the next step with coefficient +expand (clip_fft.py:276-280: `loss += a.expand * sim_func(out_enc, prev_enc)`)."""
+        if not self.expand > 0:
+            return
+        if ops._sim_key(self.sim) == 'ang':
+            raise NotImplementedError("--expand with the 'ang' similarity is not supported in the fused engine")
+        enc_rows = self.enc if enc_rows is None else enc_rows
+        D = self.targets.shape[1]
+        row0 = self.n_broadcast + (len(self.coef) - 1 - self.n_broadcast) * self.S + self.lo
+        self.targets[row0:row0 + self.S_loc].copy_(enc_rows[:self.S_loc].reshape(-1, D))
+        if self.coef[-1] != self.expand:
+            self.coef[-1] = self.expand
+            self.dcoef[-1:].fill_(self.expand)
+            self.hcoef = _ffi.floats(self.coef)
 
     # ------------------------------------------------------------------
     def draw(self):
@@ -173,6 +192,8 @@ class Engine:
         if self.rgb_priors is not None and self.rank == 0:       # illustrip.py:438-440; replicated term -> one rank adds it
             L.call('aph_rgb_priors', ops.ptr(self.rgb), self.h, self.w, float(self.rgb_priors[0]), float(self.rgb_priors[1]), 1.0,
                    ops.ptr(self.prior_ws), ops.ptr(self.loss), ops.ptr(self.grgb), st)
+        if self.sharp != 0 and self.kind != 'dwt' and self.rank == 0:      # `a.sharp != 0 and a.dwt is not True` (clip_fft.py:269)
+            L.call('aph_rgb_sharp', ops.ptr(self.rgb), self.h, self.w, -self.sharp, ops.ptr(self.prior_ws), ops.ptr(self.loss), ops.ptr(self.grgb), st)
         if self.kind == 'fft':
             L.call('aph_synth_fft_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.raw), ops.ptr(self.scale),
                    1.0, cc, int(self.decorrelate), ops.ptr(self.grad), st)

@@ -214,7 +214,9 @@ def sim_loss(enc, targets, coef, sim_type='mix', denom=None, gscale=1.0, lib=Non
     """-> (loss [1] device tensor, genc [S,D]);  targets [T,D] broadcast embeddings, per_sample: optional
     [Tp, s_total, D] per-cut targets (coef lists broadcast ones first), coef: python floats (sign*weight)"""
     L = _L(lib, enc, targets)
-    _chk(enc, torch.float32, 'enc'); _chk(targets, torch.float32, 'targets')
+    _chk(enc, torch.float32, 'enc')
+    if targets is not None:
+        _chk(targets, torch.float32, 'targets')
     S, D = enc.shape
     nb = 0 if targets is None else targets.shape[0]
     T = nb + (0 if per_sample is None else per_sample.shape[0])

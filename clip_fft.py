@@ -237,10 +237,9 @@ def main(argv=None):
     tempdir = os.path.join(a.out_dir, out_name)
     os.makedirs(tempdir, exist_ok=True)
 
-    fused = a.sharp == 0 and a.enforce == 0 and a.expand == 0 and a.aest == 0 and a.sync == 0
-    if not fused:
-        raise SystemExit(' --sharp/--enforce/--expand/--aest/--sync run through the autograd drop-in API; '
-                         'see examples in tests/test_gpu_step.py (not wired into this CLI yet)')
+    if a.enforce != 0 or a.aest != 0 or a.sync != 0:
+        raise SystemExit(' --enforce (second sampler + ViT pass), --aest (needs the aesthetic head weights) and --sync (LPIPS) are not '
+                         'part of the fused MI355X step; the drop-in autograd API (aphantasia_amd.utils / .clip) composes with torch ops for them')
     h, w = a.size
     if a.dwt is True:
         pk = dict(param_kind='dwt', dwt=image_f.synth)
@@ -249,12 +248,12 @@ def main(argv=None):
         pk = dict(param_kind='fft')
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, **pk)
+                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), **pk)
+                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     gamma = 1.0
@@ -266,6 +265,9 @@ def main(argv=None):
         if a.noise > 0 and a.dwt is not True:
             shift = (a.noise * torch.rand(1, 1, h, w // 2 + 1, 1)).reshape(h, w // 2 + 1).cuda().contiguous()
         e.step(lr=lr_cur, shift=shift)
+        if a.expand > 0:                                                                # clip_fft.py:276-280: prev_enc = out_enc.detach()
+            for other in (eng, eng2):
+                if other is not None: other.set_prev_enc(e.enc)
         if i % a.opt_step == 0 and writer is not None:
             img = e.synthesize(a.contrast)                                              # clip_fft.py:298-299
             writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)

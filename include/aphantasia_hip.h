@@ -66,6 +66,10 @@ size_t aph_rgb_priors_ws_bytes(void);
 int aph_rgb_priors(const float* d_rgb, int H, int W, float t_mean, float t_std, float weight, void* d_ws, float* d_loss,
                    float* d_rgb_grad, void* stream);
 
+/* clip_fft.py:269-270 (`--sharp`): weight * derivat(rgb, 'naiv') (utils.py:265-268), value into *d_loss and gradient into
+ * d_rgb_grad (both nullable, accumulated); the reference subtracts, so pass weight = -sharp.  d_ws as for aph_rgb_priors. */
+int aph_rgb_sharp(const float* d_rgb, int H, int W, float weight, void* d_ws, float* d_loss, float* d_rgb_grad, void* stream);
+
 /* ---- wavelet parameteriser: aphantasia/image.py:33-80 (dwt_image) over pytorch_wavelets.DWTInverse ------- */
 /* One synthesis level (lowlevel.SFB2D, mode 'symmetric').  d_ll [C,ll_h,ll_w] running low band (ll_h in {h,h+1}:
  * the extra row/col DWTInverse.forward drops is ignored), d_highs [C,3,h,w] = (LH,HL,HH) of this level,

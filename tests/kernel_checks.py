@@ -260,3 +260,26 @@ def check_rgb_priors(lib, dev):
         assert abs(loss.item() - 0.25 - 2.0 * want.item()) < 1e-6
         err = (grad.cpu() - base - 2.0 * x.grad.reshape(3, h, w)).abs().max().item()
         assert err < 1e-4 * (2.0 * x.grad.abs().max().item() + 1e-4), err
+
+
+def check_rgb_sharp(lib, dev):
+    """aph_rgb_sharp vs torch autograd on utils.py:265-268 derivat(img, 'naiv')"""
+    from aphantasia_amd import _ffi
+    L = lib if lib is not None else _ffi.lib()
+    g = torch.Generator().manual_seed(6)
+    for (h, w) in ((19, 33), (64, 130)):
+        x = torch.rand(1, 3, h, w, generator=g)
+        x[0, 1, 3:6, 4:9] = 0.5                                   # flat patch: ties (sub-gradient 0)
+        x.requires_grad_(True)
+        dx = torch.mean(torch.abs(x[:, :, :, 1:] - x[:, :, :, :-1]))
+        dy = torch.mean(torch.abs(x[:, :, 1:, :] - x[:, :, :-1, :]))
+        want = 0.5 * (dx + dy)
+        want.backward()
+        rgb = x.detach().reshape(3, h, w).to(dev).contiguous()
+        grad = torch.zeros(3, h, w, device=dev)
+        loss = torch.zeros(1, device=dev)
+        ws = torch.empty(int(L.cdll.aph_rgb_priors_ws_bytes()) // 8, dtype=torch.float64, device=dev)
+        L.call('aph_rgb_sharp', ops.ptr(rgb), h, w, -0.7, ops.ptr(ws), ops.ptr(loss), ops.ptr(grad), ops._stream(rgb))
+        assert abs(loss.item() + 0.7 * want.item()) < 1e-6
+        err = (grad.cpu() + 0.7 * x.grad.reshape(3, h, w)).abs().max().item()
+        assert err < 1e-5 * x.grad.abs().max().item(), err

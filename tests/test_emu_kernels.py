@@ -94,3 +94,7 @@ def test_vit_long_sequences(emu, res):
 
 def test_rgb_priors(emu):
     K.check_rgb_priors(emu, 'cpu')
+
+
+def test_rgb_sharp(emu):
+    K.check_rgb_sharp(emu, 'cpu')

@@ -115,3 +115,7 @@ def test_vit_base(name):
 
 def test_rgb_priors():
     K.check_rgb_priors(None, DEV)
+
+
+def test_rgb_sharp():
+    K.check_rgb_sharp(None, DEV)

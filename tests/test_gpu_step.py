@@ -242,3 +242,45 @@ def test_cli_resume_from_image_and_pt(tmp_path):
     assert len(frames) == 3
     clip_fft.main(['-t', 'cat', '-nv', '--seed', '0', '--steps', '2', '--samples', '12', '--size', '128-96', '--resume', os.path.join(out, pts[0]),
                    '--out_dir', os.path.join(tmp_path, 'out2'), '--no_save'])
+
+
+def test_sharp_and_expand_terms_vs_autograd_api(model):
+    """clip_fft.py:269-270 (--sharp) and :276-280 (--expand) in the fused engine vs the same terms written with torch ops
+    on the drop-in autograd API, three Adam steps"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd.image import fft_image, to_valid_rgb
+    from aphantasia_amd.utils import slice_imgs, sim_func
+    from aphantasia_amd import transforms
+    h, w, S, sharp, expand = 192, 256, 4, 0.6, 0.5
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+
+    def derivat_naiv(img):                      # utils.py:265-268
+        dx = torch.mean(torch.abs(img[:, :, :, 1:] - img[:, :, :, :-1]))
+        dy = torch.mean(torch.abs(img[:, :, 1:, :] - img[:, :, :-1, :]))
+        return 0.5 * (dx + dy)
+
+    seed_all(0)
+    params, image_f, _ = fft_image([1, 3, h, w], 0.07, 1.5, None)
+    p0 = params[0].detach().clone()
+    rgb_f = to_valid_rgb(image_f, colors=1.8)
+    opt = torch.optim.Adam(params, 0.05, betas=(0.0, 0.999))
+    want, prev = [], None
+    for i in range(3):
+        seed_all(10 + i)
+        img_out = rgb_f()
+        out_enc = model.encode_image(slice_imgs([img_out], S, 224, transforms.normalize(), 'uniform', 0.4)[0])
+        loss = -1.0 * sim_func(target.to(DEV), out_enc, 'mix') - sharp * derivat_naiv(img_out)
+        if i > 0:
+            loss = loss + expand * sim_func(prev, out_enc, 'mix')
+        prev = out_enc.detach().clone()
+        opt.zero_grad(); loss.backward(); opt.step()
+        want.append(float(loss))
+    eng = Engine(p0.clone(), h, w, model, S, [(target, -1.0)], transform=transforms.normalize(), rng='reference', sharp=sharp, expand=expand)
+    got = []
+    for i in range(3):
+        seed_all(10 + i)
+        got.append(float(eng.step()))
+        eng.set_prev_enc()
+    assert np.abs(np.array(got) - np.array(want)).max() < 2e-4, (got, want)
+    d = (eng.params.reshape(-1) - params[0].detach().reshape(-1)).abs()
+    assert d.mean().item() < 2e-4, d.mean().item()
