@@ -35,7 +35,7 @@ class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0):
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -61,6 +61,7 @@ class Engine:
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
         self.sharp, self.expand = float(sharp), float(expand)       # clip_fft.py:269-270, :276-280
+        self.enforce = float(enforce)                               # clip_fft.py:271-275
         self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
         self.cc = colcorr_t(colors).flatten().tolist()
@@ -109,6 +110,13 @@ class Engine:
         self.geometric = isinstance(transform, Transform) and transform.geometric
         self.aug = torch.empty(Sl, _ffi.APH_AUG_STRIDE, **f32) if self.geometric else None
         self.tmp = torch.empty(2 * Sl * 3 * self.size * self.size, **f32) if self.geometric else None
+        if self.enforce != 0:          # second, independently drawn set of cuts of the same image
+            self.table2 = torch.empty_like(self.table)
+            self.aug2 = torch.empty_like(self.aug) if self.geometric else None
+            self.enc2, self.genc2, self.grgb2 = torch.empty_like(self.enc), torch.empty_like(self.genc), torch.empty_like(self.grgb)
+            self.loss2 = torch.zeros(1, **f32)
+            self.ws2 = torch.empty(Sl * 3, **f32)
+            self.enf_coef = torch.tensor([-self.enforce], **f32)
 
     def state(self):
         return self._state
@@ -183,9 +191,14 @@ class Engine:
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
                    len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
+            if self.enforce != 0:
+                self._enqueue_enforce(L, st, Sl)
             self.visual.handle.backward(self.genc, Sl, self.gpatch, 1.0 / LOSS_SCALE)
             L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), 1.0, ops.ptr(self.table), ops.ptr(self.aug),
                    ops.ptr(self.tmp), ops.ptr(self.grgb), _ffi.APH_OUT_PATCH_F16, st)
+            if self.enforce != 0:
+                self.grgb.add_(self.grgb2)
+                self.loss.add_(self.loss2)
         else:
             self.grgb.zero_()
             self.loss.zero_()
@@ -204,6 +217,31 @@ class Engine:
         else:
             L.call('aph_synth_spatial_bwd', self.plan.handle, ops.ptr(self.grgb), 1.0, ops.ptr(self.rgb), ops.ptr(self.params), 1.0, fixed_div, cc,
                    int(self.decorrelate), ops.ptr(self.grad), st)
+
+    def _enqueue_enforce(self, L, st, Sl):
+        """--enforce (clip_fft.py:271-275): `loss -= a.enforce * sim_func(out_enc, out_enc2)` with out_enc2 from a second,
+        independently drawn slice_imgs of the same image.  Both encodings carry gradient.  The ViT handle keeps the
+        activations of ONE forward, so: forward the second set, take its backward, then recompute the first set's forward
+        (its backward follows in the caller): 3 forwards + 2 backwards instead of a second 2.5 GB arena."""
+        code = _ffi.SIM_TYPES[ops._sim_key(self.sim)]
+        D = self.enc.shape[1]
+        hc = _ffi.floats([-self.enforce])
+
+        def pair_term(enc, other, loss, genc):      # value + d/d enc of -enforce * sim(enc[s], other[s]) (mean over the GLOBAL S cuts)
+            L.call('aph_sim_loss', ops.ptr(enc), Sl, D, ops.ptr(other), ops.ptr(self.enf_coef), hc, 1, 0, Sl, 0, code, float(self.S),
+                   LOSS_SCALE, ops.ptr(self.ws2), ops.ptr(loss), ops.ptr(genc), st)
+        L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table2), ops.ptr(self.aug2), ops.ptr(self.tmp),
+               ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
+        self.visual._forward_patches(self.patches, Sl, self.enc2)
+        pair_term(self.enc2, self.enc, self.loss2, self.genc2)
+        self.visual.handle.backward(self.genc2, Sl, self.gpatch, 1.0 / LOSS_SCALE)
+        L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), 1.0, ops.ptr(self.table2), ops.ptr(self.aug2),
+               ops.ptr(self.tmp), ops.ptr(self.grgb2), _ffi.APH_OUT_PATCH_F16, st)
+        pair_term(self.enc, self.enc2, self.loss2, self.genc2)       # same value again; genc2 now = d/d enc (first set)
+        self.genc.add_(self.genc2)
+        L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table), ops.ptr(self.aug), ops.ptr(self.tmp),
+               ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
+        self.visual._forward_patches(self.patches, Sl, self.enc)
 
     def _enqueue_adam(self):
         self.lib.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
@@ -226,10 +264,13 @@ class Engine:
                 self._enqueue_adam()
         self._graphs = (g1, g2)
 
-    def step(self, table=None, augs=None, lr=None, shift=None):
+    def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
         if table is None:
             table, augs = self.draw()
+        table2 = augs2 = None
+        if self.enforce != 0:
+            table2, augs2 = self.draw() if tables2 is None else tables2          # the second slice_imgs of the same train(i)
         Sl = self.S_loc
         self._state['step'][0] += 1
         self._calls += 1
@@ -241,6 +282,11 @@ class Engine:
             if self.geometric:
                 packed = torch.from_numpy(np.ascontiguousarray(augs[self.lo:self.hi])) if isinstance(augs, np.ndarray) else pack_aug(augs[self.lo:self.hi])
                 self.aug.copy_(packed, non_blocking=True)
+            if self.enforce != 0:
+                self.table2.copy_(torch.from_numpy(np.ascontiguousarray(table2[self.lo:self.hi])), non_blocking=True)
+                if self.geometric:
+                    packed = torch.from_numpy(np.ascontiguousarray(augs2[self.lo:self.hi])) if isinstance(augs2, np.ndarray) else pack_aug(augs2[self.lo:self.hi])
+                    self.aug2.copy_(packed, non_blocking=True)
         use_graph = self.use_graph and shift is None and self.params.is_cuda
         if use_graph and self._graphs is None and self._calls > 2:      # two eager steps first (one-time kernel attributes, allocator warm-up)
             self._capture()

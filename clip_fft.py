@@ -237,9 +237,9 @@ def main(argv=None):
     tempdir = os.path.join(a.out_dir, out_name)
     os.makedirs(tempdir, exist_ok=True)
 
-    if a.enforce != 0 or a.aest != 0 or a.sync != 0:
-        raise SystemExit(' --enforce (second sampler + ViT pass), --aest (needs the aesthetic head weights) and --sync (LPIPS) are not '
-                         'part of the fused MI355X step; the drop-in autograd API (aphantasia_amd.utils / .clip) composes with torch ops for them')
+    if a.aest != 0 or a.sync != 0:
+        raise SystemExit(' --aest (needs the aesthetic head weights) and --sync (LPIPS) are not part of the fused MI355X step; '
+                         'the drop-in autograd API (aphantasia_amd.utils / .clip) composes with torch ops for them')
     h, w = a.size
     if a.dwt is True:
         pk = dict(param_kind='dwt', dwt=image_f.synth)
@@ -248,12 +248,12 @@ def main(argv=None):
         pk = dict(param_kind='fft')
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, **pk)
+                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, **pk)
+                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     gamma = 1.0

@@ -284,3 +284,33 @@ def test_sharp_and_expand_terms_vs_autograd_api(model):
     assert np.abs(np.array(got) - np.array(want)).max() < 2e-4, (got, want)
     d = (eng.params.reshape(-1) - params[0].detach().reshape(-1)).abs()
     assert d.mean().item() < 2e-4, d.mean().item()
+
+
+@pytest.mark.parametrize('tf', ['none', 'fast'])
+def test_enforce_term_vs_autograd_api(model, tf):
+    """clip_fft.py:271-275 (--enforce): second independently drawn set of cuts, pairwise similarity with gradient into both
+    encodings -- fused engine (forward B, backward B, recompute A, backward A) vs torch autograd over the drop-in API"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd.image import fft_image, to_valid_rgb
+    from aphantasia_amd.utils import slice_imgs, sim_func
+    from aphantasia_amd import transforms
+    h, w, S, enforce = 192, 256, 4, 0.7
+    trf = transforms.normalize() if tf == 'none' else transforms.transforms_fast
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    seed_all(0)
+    params, image_f, _ = fft_image([1, 3, h, w], 0.07, 1.5, None)
+    p0 = params[0].detach().clone()
+    rgb_f = to_valid_rgb(image_f, colors=1.8)
+    seed_all(21)
+    out_enc = model.encode_image(slice_imgs([rgb_f()], S, 224, trf, 'uniform', 0.4)[0])
+    loss = -1.0 * sim_func(target.to(DEV), out_enc, 'mix')
+    out_enc2 = model.encode_image(slice_imgs([rgb_f()], S, 224, trf, 'uniform', 0.4)[0])
+    loss = loss - enforce * sim_func(out_enc, out_enc2, 'mix')
+    loss.backward()
+    eng = Engine(p0.clone(), h, w, model, S, [(target, -1.0)], transform=trf, rng='reference', enforce=enforce)
+    seed_all(21)
+    got = float(eng.step())
+    assert abs(got - float(loss)) < 1e-4, (got, float(loss))
+    g = params[0].grad.reshape(-1)
+    err = (eng.grad.reshape(-1) - g).abs().max().item()
+    assert err < 2e-2 * g.abs().max().item(), (err, g.abs().max().item())
