@@ -14,6 +14,8 @@ by the global S, so the sum of the partial gradients is the single-GPU gradient.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -296,6 +298,7 @@ class Engine:
             if self.world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
+            if self._graphs[1] is not None:
                 self._graphs[1].replay()
             return self.loss
         self._enqueue_grad(shift)

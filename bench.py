@@ -71,13 +71,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != a.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    # debugging aid for single-GPU boxes: APH_BENCH_BACKEND=gloo puts every rank on cuda:0 and reduces through the host
+    backend = os.environ.get('APH_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from aphantasia_amd import clip as aclip, transforms
     from aphantasia_amd.engine import Engine

@@ -314,3 +314,27 @@ def test_enforce_term_vs_autograd_api(model, tf):
     g = params[0].grad.reshape(-1)
     err = (eng.grad.reshape(-1) - g).abs().max().item()
     assert err < 2e-2 * g.abs().max().item(), (err, g.abs().max().item())
+
+
+def test_step_is_bitwise_reproducible(model):
+    """no atomics, fixed-order reductions, ordered split-K: two runs from the same seeds give the same bits (also a tripwire
+    for LDS / barrier races in the pipelined GEMMs)"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+
+    def run(graph):
+        seed_all(0)
+        h, w = 360, 640
+        params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+        eng = Engine(params, h, w, model, 24, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=0.4, use_graph=graph)
+        for _ in range(5):
+            eng.step()
+        torch.cuda.synchronize()
+        return eng.params.clone(), eng.grad.clone(), eng.gpatch.clone(), float(eng.loss)
+    a, b, c = run(False), run(False), run(True)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[:3], c[:3]):          # hipGraph replay == eager launches
+        assert torch.equal(x, y)
+    assert a[3] == b[3] == c[3]
