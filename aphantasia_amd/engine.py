@@ -107,6 +107,8 @@ class Engine:
         self.prior_ws = torch.empty(int(self.lib.cdll.aph_rgb_priors_ws_bytes()) // 8, device=self.dev, dtype=torch.float64)
         self.ws = torch.empty(Sl * (len(targets) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
+        self._own_stream = None
+        self._stage, self._stage_i = None, 0       # pinned host ring for the per-step H2D refreshes (built lazily, GPU only)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
         self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
         self.geometric = isinstance(transform, Transform) and transform.geometric
@@ -245,6 +247,38 @@ class Engine:
                ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
         self.visual._forward_patches(self.patches, Sl, self.enc)
 
+    def _upload(self, hy, table, augs, table2, augs2):
+        """Refresh the device-side per-step inputs (Adam scalars, crop table, augment table).  On the GPU the values go
+        through a ring of PINNED host buffers owned by the engine: the async copies never read from a temporary, and the
+        host may run ahead of the device by up to the ring depth."""
+        Sl = self.S_loc
+        rows = lambda a: torch.from_numpy(np.ascontiguousarray(a[self.lo:self.hi]))
+        packed = lambda a: rows(a) if isinstance(a, np.ndarray) else pack_aug(a[self.lo:self.hi])
+        items = [(self.hyper, torch.tensor(hy, dtype=torch.float32))]
+        if Sl > 0:
+            items.append((self.table, rows(table)))
+            if self.geometric:
+                items.append((self.aug, packed(augs)))
+            if self.enforce != 0:
+                items.append((self.table2, rows(table2)))
+                if self.geometric:
+                    items.append((self.aug2, packed(augs2)))
+        if not self.params.is_cuda:
+            for dst, src in items:
+                dst.copy_(src)
+            return
+        if self._stage is None:
+            self._stage = [dict(bufs=[torch.empty(d.shape, dtype=d.dtype).pin_memory() for d, _ in items], ev=None) for _ in range(4)]
+        slot = self._stage[self._stage_i % len(self._stage)]
+        self._stage_i += 1
+        if slot['ev'] is not None:
+            slot['ev'].synchronize()            # the copies issued from this slot four steps ago have been consumed
+        for (dst, src), buf in zip(items, slot['bufs']):
+            buf.copy_(src)
+            dst.copy_(buf, non_blocking=True)
+        slot['ev'] = torch.cuda.Event()
+        slot['ev'].record()
+
     def _enqueue_adam(self):
         self.lib.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
                       ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), ops._stream(self.params))
@@ -259,15 +293,26 @@ class Engine:
             self._enqueue_grad(None)
             if self.world == 1:
                 self._enqueue_adam()
-        g2 = None
-        if self.world > 1:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                self._enqueue_adam()
-        self._graphs = (g1, g2)
+        self._graphs = (g1, None)          # world > 1: the Adam launch follows the all-reduce eagerly (one kernel)
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
+        if self.world > 1 and self.params.is_cuda:
+            # Multi-rank: never launch on the legacy default (NULL) stream.  hipGraph replays on the NULL stream next to a
+            # collective backend's own streams (event waits in both directions) gave NaN gradients after a mid-run device
+            # synchronize (measured with two ranks over gloo; gone on a dedicated stream).  The caller's stream is fenced
+            # on entry and exit, so results are visible to it as before.
+            if self._own_stream is None:
+                self._own_stream = torch.cuda.Stream(device=self.dev)
+            cur = torch.cuda.current_stream(self.dev)
+            self._own_stream.wait_stream(cur)
+            with torch.cuda.stream(self._own_stream):
+                out = self._step(table, augs, lr, shift, tables2)
+            cur.wait_stream(self._own_stream)
+            return out
+        return self._step(table, augs, lr, shift, tables2)
+
+    def _step(self, table, augs, lr, shift, tables2):
         if table is None:
             table, augs = self.draw()
         table2 = augs2 = None
@@ -278,17 +323,7 @@ class Engine:
         self._calls += 1
         lr = self.lr if lr is None else lr
         hy = ops.adam_hyper(self._state['step'][0], lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
-        self.hyper.copy_(torch.tensor(hy, dtype=torch.float32), non_blocking=True)
-        if Sl > 0:
-            self.table.copy_(torch.from_numpy(np.ascontiguousarray(table[self.lo:self.hi])), non_blocking=True)
-            if self.geometric:
-                packed = torch.from_numpy(np.ascontiguousarray(augs[self.lo:self.hi])) if isinstance(augs, np.ndarray) else pack_aug(augs[self.lo:self.hi])
-                self.aug.copy_(packed, non_blocking=True)
-            if self.enforce != 0:
-                self.table2.copy_(torch.from_numpy(np.ascontiguousarray(table2[self.lo:self.hi])), non_blocking=True)
-                if self.geometric:
-                    packed = torch.from_numpy(np.ascontiguousarray(augs2[self.lo:self.hi])) if isinstance(augs2, np.ndarray) else pack_aug(augs2[self.lo:self.hi])
-                    self.aug2.copy_(packed, non_blocking=True)
+        self._upload(hy, table, augs, table2, augs2)
         use_graph = self.use_graph and shift is None and self.params.is_cuda
         if use_graph and self._graphs is None and self._calls > 2:      # two eager steps first (one-time kernel attributes, allocator warm-up)
             self._capture()
@@ -298,8 +333,7 @@ class Engine:
             if self.world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
-            if self._graphs[1] is not None:
-                self._graphs[1].replay()
+                self._enqueue_adam()
             return self.loss
         self._enqueue_grad(shift)
         if self.world > 1:
