@@ -57,6 +57,16 @@ __device__ __forceinline__ void emit(void* out, int s, int c, int i, int j, int 
   }
 }
 
+// backward-only layout: patch-major like APH_OUT_PATCH_F16 but the gradient elements are f16 (the ViT input-gradient
+// written by aph_vit_backward_h, still carrying the loss scale)
+template <int OUT>
+__device__ __forceinline__ float gload(const void* __restrict__ g, size_t o) {
+  if (OUT == APH_GRAD_PATCH_F16) return (float)reinterpret_cast<const half_t*>(g)[o];
+  return reinterpret_cast<const float*>(g)[o];
+}
+template <int OUT>
+struct is_patch { static constexpr bool v = OUT == APH_OUT_PATCH_F16 || OUT == APH_GRAD_PATCH_F16; };
+
 // gradient w.r.t. the un-normalised cut pixel (c,i,j) of cut s, read from `gout` in layout OUT
 template <int OUT>
 __device__ __forceinline__ float fetch_grad(const float* __restrict__ gout, int s, int c, int i, int j, int size, int patch) {
@@ -67,14 +77,14 @@ __device__ __forceinline__ float fetch_grad(const float* __restrict__ gout, int 
 
 // all three channels of cut pixel (i, j): one index computation (the patch-major index needs integer divisions)
 template <int OUT>
-__device__ __forceinline__ void fetch_grad3(const float* __restrict__ gout, int s, int i, int j, int size, int patch, float g[3]) {
-  if (OUT == APH_OUT_PATCH_F16) {
+__device__ __forceinline__ void fetch_grad3(const void* __restrict__ gout, int s, int i, int j, int size, int patch, float g[3]) {
+  if (is_patch<OUT>::v) {
     const size_t o = patch_index(s, 0, i, j, size, patch);
     const int pp = patch * patch;
-    g[0] = gout[o] / kClipStd[0]; g[1] = gout[o + pp] / kClipStd[1]; g[2] = gout[o + 2 * pp] / kClipStd[2];
+    g[0] = gload<OUT>(gout, o) / kClipStd[0]; g[1] = gload<OUT>(gout, o + pp) / kClipStd[1]; g[2] = gload<OUT>(gout, o + 2 * pp) / kClipStd[2];
   } else {
     const size_t o = ((size_t)s * 3 * size + i) * size + j, nn = (size_t)size * size;
-    g[0] = gout[o]; g[1] = gout[o + nn]; g[2] = gout[o + 2 * nn];
+    g[0] = gload<OUT>(gout, o); g[1] = gload<OUT>(gout, o + nn); g[2] = gload<OUT>(gout, o + 2 * nn);
     if (OUT == APH_OUT_NCHW_NORM) { g[0] /= kClipStd[0]; g[1] /= kClipStd[1]; g[2] /= kClipStd[2]; }
   }
 }
@@ -151,12 +161,12 @@ struct AdjEntry {
 // separable offset parts of gradient element (i, j) in layout OUT (channel/cut base added by the caller)
 template <int OUT>
 __device__ __forceinline__ int grad_rowpart(int i, int size, int p) {
-  if (OUT == APH_OUT_PATCH_F16) return (i / p) * (size / p) * (3 * p * p) + (i % p) * p;
+  if (is_patch<OUT>::v) return (i / p) * (size / p) * (3 * p * p) + (i % p) * p;
   return i * size;
 }
 template <int OUT>
 __device__ __forceinline__ int grad_colpart(int j, int size, int p) {
-  if (OUT == APH_OUT_PATCH_F16) return (j / p) * (3 * p * p) + (j % p);
+  if (is_patch<OUT>::v) return (j / p) * (3 * p * p) + (j % p);
   return j;
 }
 
@@ -176,7 +186,7 @@ __device__ __forceinline__ float tap_weight(float scale, int i, int cs, int q) {
 }
 
 template <int OUT>
-__global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* __restrict__ gout, float gscale,
+__global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __restrict__ gout, float gscale,
                                                                   const int* __restrict__ table, float* __restrict__ grgb, Geom g) {
   constexpr int MAXV = 1024, NB = 8;
   __shared__ int vlist[MAXV];
@@ -189,8 +199,8 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* _
   const int nay = (g.Hp + g.H - 1) / g.H, nax = (g.Wp + g.W - 1) / g.W;     // aliases per axis (1 without overscan)
   const int nvirt = g.S * nay * nax;
   const int ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
-  const int cchan = OUT == APH_OUT_PATCH_F16 ? g.patch * g.patch : g.size * g.size;
-  const int ccut = OUT == APH_OUT_PATCH_F16 ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
+  const int cchan = is_patch<OUT>::v ? g.patch * g.patch : g.size * g.size;
+  const int ccut = is_patch<OUT>::v ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
   for (int vbase = 0; vbase < nvirt; vbase += MAXV) {
     // ---- 1. ordered compaction by wave 0
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* _
           const int Y = wrap(y + g.py0, g.H) + ay * g.H, X = wrap(x + g.px0, g.W) + ax * g.W;
           const int yc = Y - oy, xc = X - ox;
           if (live && Y < g.Hp && X < g.Wp && yc >= 0 && yc < cs && xc >= 0 && xc < cs) {
-            const float* gb = gout + (size_t)s * ccut;
+            const size_t gb = (size_t)s * ccut;
             for (int i = 0; i < g.size; ++i) {
               const float wy = tap_weight(scale, i, cs, yc);
               if (wy == 0.f) continue;
@@ -278,9 +288,9 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* _
                 const float wx = tap_weight(scale, j, cs, xc);
                 if (wx == 0.f) continue;
                 const int o = grad_rowpart<OUT>(i, g.size, g.patch) + grad_colpart<OUT>(j, g.size, g.patch);
-                acc0 += wy * wx * gb[o];
-                acc1 += wy * wx * gb[o + cchan];
-                acc2 += wy * wx * gb[o + 2 * cchan];
+                acc0 += wy * wx * gload<OUT>(gout, gb + o);
+                acc1 += wy * wx * gload<OUT>(gout, gb + o + cchan);
+                acc2 += wy * wx * gload<OUT>(gout, gb + o + 2 * cchan);
               }
             }
           }
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* _
         }
         const AdjEntry re = ent[vb][ty], ce = ent[vb][16 + tx];
         if (re.w[0] == 0.f && re.w[1] == 0.f) continue;     // (a run starts with its first non-zero weight)
-        const float* gb = gout + (size_t)s * ccut;
+        const size_t gb = (size_t)s * ccut;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           if (re.w[a] == 0.f) continue;
@@ -297,9 +307,9 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const float* _
             if (ce.w[bq] == 0.f) continue;
             const float w = re.w[a] * ce.w[bq];
             const int o = re.off[a] + ce.off[bq];
-            acc0 += w * gb[o];
-            acc1 += w * gb[o + cchan];
-            acc2 += w * gb[o + 2 * cchan];
+            acc0 += w * gload<OUT>(gout, gb + o);
+            acc1 += w * gload<OUT>(gout, gb + o + cchan);
+            acc2 += w * gload<OUT>(gout, gb + o + 2 * cchan);
           }
         }
       }
@@ -434,7 +444,7 @@ __device__ __forceinline__ float tap_hits(const Tap& t, int py, int px) {
 // cut; the output pixels whose bilinear footprint contains p lie in the inverse-rotated 2x2 square around p.
 // Each candidate's footprint is re-derived with the forward's own arithmetic.
 template <int OUT>
-__global__ void rotate_emit_adjoint_kernel(const float* __restrict__ gout, const float* __restrict__ aug,
+__global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const float* __restrict__ aug,
                                            float* __restrict__ dA, float* __restrict__ dB, int n, int patch) {
   const int s = blockIdx.y;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
@@ -540,12 +550,12 @@ using namespace aph;
 
 static Geom to_geom(const aph_sample_geom* g) { return Geom{g->H, g->W, g->Hp, g->Wp, g->py0, g->px0, g->S, g->size, g->patch}; }
 
-static int check_geom(const aph_sample_geom* g, int out_mode, const char* who) {
+static int check_geom(const aph_sample_geom* g, int out_mode, const char* who, int max_mode = 2) {
   if (!g) return aph_fail(APH_ERR_ARG, "%s: null geometry", who);
   if (g->S < 1 || g->size < 1 || g->H < 1 || g->W < 1 || g->Hp < g->H || g->Wp < g->W)
     return aph_fail(APH_ERR_ARG, "%s: bad geometry S=%d size=%d H=%d W=%d Hp=%d Wp=%d", who, g->S, g->size, g->H, g->W, g->Hp, g->Wp);
-  if (out_mode < 0 || out_mode > 2) return aph_fail(APH_ERR_ARG, "%s: bad out_mode %d", who, out_mode);
-  if (out_mode == APH_OUT_PATCH_F16 && (g->patch < 1 || g->size % g->patch))
+  if (out_mode < 0 || out_mode > max_mode) return aph_fail(APH_ERR_ARG, "%s: bad out_mode %d", who, out_mode);
+  if (out_mode >= APH_OUT_PATCH_F16 && (g->patch < 1 || g->size % g->patch))
     return aph_fail(APH_ERR_ARG, "%s: size %d not divisible by patch %d", who, g->size, g->patch);
   return APH_OK;
 }
@@ -578,10 +588,10 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   APH_CATCH
 }
 
-int aph_sample_bwd(const aph_sample_geom* gg, const float* gout, float gscale, const int32_t* table, const float* aug,
+int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, const int32_t* table, const float* aug,
                    float* tmp, float* grgb, int out_mode, void* stream_) {
   APH_TRY
-  if (int e = check_geom(gg, out_mode, "aph_sample_bwd")) return e;
+  if (int e = check_geom(gg, out_mode, "aph_sample_bwd", APH_GRAD_PATCH_F16)) return e;
   if (!gout || !table || !grgb || (aug && !tmp)) return aph_fail(APH_ERR_ARG, "aph_sample_bwd: null argument");
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
@@ -590,7 +600,8 @@ int aph_sample_bwd(const aph_sample_geom* gg, const float* gout, float gscale, c
   if (!aug) {
     if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_RAW>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
     else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_NORM>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
-    else APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_PATCH_F16>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
+    else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_PATCH_F16>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
+    else APH_LAUNCH(crop_resize_adjoint_kernel<APH_GRAD_PATCH_F16>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
     return aph_check_launch("aph_sample_bwd");
   }
   const size_t per = (size_t)g.S * 3 * n * n;
@@ -599,9 +610,10 @@ int aph_sample_bwd(const aph_sample_geom* gg, const float* gout, float gscale, c
   const dim3 grid((n * n + 255) / 256, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
-  else APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
+  else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
+  else APH_LAUNCH(rotate_emit_adjoint_kernel<APH_GRAD_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   APH_LAUNCH(persp_adjoint_kernel, grid, block, 0, st, (const float*)dB, aug, dA, n);
-  APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_RAW>, agrid, block, 0, st, (const float*)dA, gscale, (const int*)table, grgb, g);
+  APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_RAW>, agrid, block, 0, st, (const void*)dA, gscale, (const int*)table, grgb, g);
   return aph_check_launch("aph_sample_bwd");
   APH_CATCH
 }

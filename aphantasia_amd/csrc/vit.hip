@@ -308,8 +308,7 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
 
 // input-gradient of the last aph_vit_forward: d_genc f32 [S, output_dim] (already multiplied by the caller's
 // loss scale) -> d_patch_grad f32 [S*P, 3*patch*patch] multiplied by out_scale (pass 1/loss_scale).
-int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream_) {
-  APH_TRY
+static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_patch_grad, bool grad_f16, float out_scale, void* stream_) {
   if (!v || !d_genc || !d_patch_grad) return aph_fail(APH_ERR_ARG, "aph_vit_backward: null argument");
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
   hipStream_t st = (hipStream_t)stream_;
@@ -332,8 +331,19 @@ int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad
     launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
   }
   launch_ln_bwd<false, true>(nv, v->dx, v->x0, v->ln_pre_g, nullptr, nullptr, v->dx0_16, M, T, st);
-  vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{d_patch_grad, v->Kp, out_scale}, st);
+  if (grad_f16) vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF16Scale{(half_t*)d_patch_grad, v->Kp, out_scale}, st);
+  else vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{(float*)d_patch_grad, v->Kp, out_scale}, st);
   return aph_check_launch("aph_vit_backward");
+}
+
+int aph_vit_backward(aph_vit* v, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream_) {
+  APH_TRY
+  return vit_backward_impl(v, d_genc, S, d_patch_grad, false, out_scale, stream_);
+  APH_CATCH
+}
+int aph_vit_backward_h(aph_vit* v, const float* d_genc, int S, void* d_patch_grad_f16, float out_scale, void* stream_) {
+  APH_TRY
+  return vit_backward_impl(v, d_genc, S, d_patch_grad_f16, true, out_scale, stream_);
   APH_CATCH
 }
 

@@ -450,6 +450,11 @@ struct EpiF32 {          // out = acc * scale  (fp32)
   }
 };
 
+struct EpiF16Scale {     // out = acc * scale (f16)
+  half_t* out; int ldo; float scale;
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const { store_h8(out + (size_t)m * ldo + n, a * scale, b * scale); }
+};
+
 struct EpiResidual {     // out = res + acc + bias   (fp32 residual stream)
   float* out; const float* res; int ldo; const float* bias;
   __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {

@@ -187,7 +187,8 @@ class VitHandle:
     def backward(self, genc, S, out=None, out_scale=1.0):
         if out is None:
             out = torch.empty(S * self.P, self.Kp, dtype=torch.float32, device=genc.device)
-        self.lib.call('aph_vit_backward', self.handle, ptr(genc), int(S), ptr(out), float(out_scale), _stream(genc))
+        fn = 'aph_vit_backward_h' if out.dtype == torch.float16 else 'aph_vit_backward'        # f16 `out`: patch gradient kept in half
+        self.lib.call(fn, self.handle, ptr(genc), int(S), ptr(out), float(out_scale), _stream(genc))
         return out
 
     def __del__(self):

@@ -96,6 +96,7 @@ typedef struct aph_sample_geom {
 #define APH_OUT_NCHW_RAW 0   /* f32 [S,3,size,size], no normalisation (transform=None) */
 #define APH_OUT_NCHW_NORM 1  /* f32 [S,3,size,size], CLIP mean/std normalised (transforms.normalize) */
 #define APH_OUT_PATCH_F16 2  /* f16 [S*(size/patch)^2, 3*patch*patch] normalised = patch-embed GEMM operand */
+#define APH_GRAD_PATCH_F16 3 /* aph_sample_bwd only: gradient in the patch-major layout stored as f16 (aph_vit_backward_h) */
 
 #define APH_AUG_STRIDE 16
 /* per-cut augment row (f32 x 16): [0..7] perspective coeffs, [8] has_perspective, [9..12] erase i,j,h,w
@@ -106,10 +107,10 @@ typedef struct aph_sample_geom {
  * elements, only needed when d_aug != NULL.  out layout per out_mode. */
 int aph_sample_fwd(const aph_sample_geom* g, const float* d_rgb, const int32_t* d_table, const float* d_aug,
                    float* d_tmp, void* d_out, int out_mode, void* stream);
-/* adjoint.  d_out_grad: f32 in the layout of out_mode (patch-major f32 for APH_OUT_PATCH_F16), multiplied by
- * gscale.  d_tmp as above (overwritten).
+/* adjoint.  d_out_grad: f32 in the layout of out_mode (patch-major f32 for APH_OUT_PATCH_F16; patch-major f16 for
+ * APH_GRAD_PATCH_F16), multiplied by gscale.  d_tmp as above (overwritten).
  * Writes (does not accumulate) d_rgb_grad [3,H,W]. */
-int aph_sample_bwd(const aph_sample_geom* g, const float* d_out_grad, float gscale, const int32_t* d_table,
+int aph_sample_bwd(const aph_sample_geom* g, const void* d_out_grad, float gscale, const int32_t* d_table,
                    const float* d_aug, float* d_tmp, float* d_rgb_grad, int out_mode, void* stream);
 /* NCHW f32 [S,3,R,R] <-> patch-major (entry of model.encode_image for a caller-made batch) */
 int aph_patchify_f16(const float* d_nchw, int S, int R, int patch, void* d_patches_f16, void* stream);
@@ -129,6 +130,9 @@ int aph_vit_set_weight(aph_vit* vit, const char* name, const float* h_data, size
 int aph_vit_forward(aph_vit* vit, const void* d_patches, int S, float* d_enc, void* stream);
 /* d_genc f32 [S, output_dim] (times the caller's loss scale) -> d_patch_grad f32 [S*P, 3*patch^2] times out_scale */
 int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream);
+/* same with the patch gradient stored as f16 (keep the loss scale in it: out_scale = 1, and undo it in aph_sample_bwd's
+ * gscale with out_mode APH_GRAD_PATCH_F16): halves the bytes the sampler adjoint gathers */
+int aph_vit_backward_h(aph_vit* vit, const float* d_genc, int S, void* d_patch_grad_f16, float out_scale, void* stream);
 /* per-launch HIP-event timing of the ViT's GEMM launches (bench.py roofline): on/off, then read the sums */
 int aph_vit_profile(aph_vit* vit, int on);
 int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);

@@ -338,3 +338,22 @@ def test_step_is_bitwise_reproducible(model):
     for x, y in zip(a[:3], c[:3]):          # hipGraph replay == eager launches
         assert torch.equal(x, y)
     assert a[3] == b[3] == c[3]
+
+
+def test_f16_patch_gradient_option_is_close(model):
+    """Engine(grad_f16=True): the ViT input-gradient crosses to the sampler adjoint as loss-scaled f16 (aph_vit_backward_h +
+    APH_GRAD_PATCH_F16); one step stays within f16 rounding of the default f32 hand-over"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    outs = []
+    for f16 in (False, True):
+        seed_all(0)
+        h, w = 360, 640
+        params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+        eng = Engine(params, h, w, model, 12, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=0.4, grad_f16=f16, use_graph=False)
+        loss = float(eng.step())
+        outs.append((loss, eng.grad.clone()))
+    assert outs[0][0] == outs[1][0]
+    d = (outs[0][1] - outs[1][1]).abs().max().item()
+    assert d < 2e-3 * outs[0][1].abs().max().item(), d
