@@ -186,13 +186,6 @@ void launch_attn_bwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
 
 }  // namespace
 
-struct EpiProbe {        // experiment: full epilogue data path, stores predicated off at run time
-  float* out; int ldo; float on;
-  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
-    if (on != 0.f) { st4(out + (size_t)m * ldo + n, a); st4(out + (size_t)m * ldo + n + 4, b); }
-  }
-};
-
 extern "C" {
 
 // cfg mirrors clip.model.VisionTransformer(input_resolution, patch_size, width, layers, heads, output_dim)
@@ -383,12 +376,12 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 }
 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
-// (0 = automatic, 1 = 64x64, 2 = 256x128, 3 = 256x256, 4 = 256x256 phased [both need N % 256 == 0], 5 = 128x128 2-stage,
-// 8 / 9 = 64x64 split-K x2 / x4, 10 = 128x128 4-stage; other codes are measurement variants used by tools/) -- unit tests and layout experiments
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 8 / 9 = 64x64 split-K x2 / x4,
+// 10 = 128x128 4-stage, 22 / 24 = 128x128 split-K x2 / x4) -- unit tests and tuning sweeps
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      tile_cfg < 0 || tile_cfg > 40 || ((tile_cfg == 3 || tile_cfg == 4) && N % 256))
+      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || (tile_cfg >= 8 && tile_cfg <= 10) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && N % 256))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
@@ -396,15 +389,7 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   hipStream_t st = (hipStream_t)stream_;
   if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 3) launch_gemm_cfg<GemmHuge>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 5) launch_gemm_cfg<GemmMid>(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 6) launch_gemm8(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 11) launch_gemm8<EpiProbe, 1>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 12) launch_gemm8<EpiProbe, 2>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 13) launch_gemm8<EpiProbe, 3>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 17) launch_gemm8<EpiProbe, 7>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
-  else if (tile_cfg == 18) launch_gemm8<EpiProbe, 8>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else if (tile_cfg == 8 || tile_cfg == 9 || tile_cfg == 22 || tile_cfg == 24) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
     static SplitKSpace sp;
     const int splits = (tile_cfg == 8 || tile_cfg == 22) ? 2 : 4;
@@ -417,7 +402,6 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
     else launch_gemm_splitk<GemmSmall>(A, lda, B, ldb, M, N, K, epi, splits, sp, st);
   }
   else if (tile_cfg == 10) launch_gemm_cfg<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 7) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, EpiProbe{d_C, N, (float)(M > (1 << 30))}, st);
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH

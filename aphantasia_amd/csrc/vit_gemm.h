@@ -3,24 +3,25 @@
 //   C[m][n] = sum_k A[m][k] * Bt[n][k]        A: [M,K] f16 row-major, Bt: [N,K] f16 row-major
 //
 // Both operands are K-contiguous, so the forward (activations x weight^T) and the dgrad (d_out x weight, using a
-// pre-transposed weight copy) run through the same kernel.  One kernel template, two tile configurations:
-//   * 256x256x64, 8 waves (2x4 of 128x64), 2-stage ring, 128 KiB LDS -- wide outputs (N >= 2304) at full batch: a CU can
-//     pull ~110 GB/s through the LDS-DMA path (measured), which a 256x128 tile needs ALL of at full MFMA rate;
-//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS  -- the full-batch shapes (M ~ 9500), N = 768;
-//   *  64x 64x64, 4 waves (2x2 of 32x32), 4-stage ring,  64 KiB LDS (2 workgroups per CU) -- whenever the large
-//     tile would leave CUs idle (per-rank shards of a multi-GPU run, small batches).
-// Structure (cdna_hip_programming.md section 5):
+// pre-transposed weight copy) run through the same kernels.  Tile configurations (launch_gemm picks one per shape):
+//   * 256x256x64 "phased" kernel (gemm8_f16_kernel): 8 waves (2x4 of 128x64), 2 x 64 KiB stages, four phases per k-tile,
+//     the two wave groups one barrier apart -- wide outputs (N >= 2304) at full batch;
+//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS -- N = 768 at full batch;
+//   * 128x128x64, 8 waves (4x2 of 32x64), 4-stage ring, 128 KiB LDS -- half-batch shards, wide outputs of small shards;
+//   *  64x 64x64, 4 waves (2x2 of 32x32), 4-stage ring,  64 KiB LDS (2 workgroups per CU) -- small M; two-pass split-K
+//     when only a handful of tiles exist (the class-row GEMMs of the last block).
+// Common structure (cdna_hip_programming.md section 5):
 //   * operands stream straight into LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass)
-//     through the ring with COUNTED vmcnt waits and a raw s_barrier -- one barrier per k-tile, 2-3 tiles in flight;
+//     with COUNTED vmcnt waits and a raw s_barrier, 2-3 k-tiles in flight;
 //   * the LDS image written by the DMA is lane-linear, so the XOR swizzle that makes every ds_read_b128 fragment
 //     fetch conflict-free (0 SQ_LDS_BANK_CONFLICT measured) is applied to the per-lane SOURCE address (rule 21);
-//   * LDS -> register fragment loads are software-pipelined one k-step (32) ahead of the MFMAs, across the barrier;
-//   * the two waves that share a SIMD issue their DMA half a k-tile apart;
+//   * ring kernels: LDS -> register fragment loads software-pipelined one k-step (32) ahead of the MFMAs, across the
+//     barrier; the two waves that share a SIMD issue their DMA half a k-tile apart;
 //   * operands are swapped at the MFMA (weights as the A fragment) and the accumulators leave through LDS, so every
 //     lane stores 8 consecutive columns of one row: whole 128-byte lines, 16/32-byte accesses;
 //   * XCD-aware tile order (T1): the column tiles that re-read one A panel run on the same XCD / L2.
-// Constraints: N % 128 == 0, K % 64 == 0 (true for every ViT-B linear); M is arbitrary (loads clamp the row,
-// stores are predicated).
+// Constraints: N % 128 == 0 (N % 256 for the phased kernel), K % 64 == 0 (true for every ViT-B linear); M is arbitrary
+// (loads clamp the row, stores are predicated).
 #pragma once
 #include "aph_device.h"
 
@@ -31,10 +32,9 @@ constexpr int GEMM_BK = 64;
 // LDS tile: [rows][8 chunks of 8 halfs]; chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7)
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_, bool PIPE_ = true>
+template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
 struct GemmCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_;
-  static constexpr bool PIPE = PIPE_;          // fragment reads software-pipelined one k-step ahead (costs a 2nd fragment set)
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   static constexpr int NWAVE = WM * WN, NTHREAD = NWAVE * 64;
   static constexpr int STAGE = (BM + BN) * GEMM_BK;                 // halfs per stage
@@ -48,9 +48,7 @@ struct GemmCfg {
   static_assert(NWAVE * EP_MT * 16 * CT_LD * 4 <= SMEM && TM % EP_MT == 0, "epilogue staging must fit in the ring");
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
 };
-using GemmHuge = GemmCfg<2, 4, 8, 4, 2, false>;   // 256 x 256, 512 threads, 128 KiB: 128 flop per L2 byte (128 acc VGPRs: one fragment set)
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
-using GemmMid = GemmCfg<2, 2, 4, 4, 2>;      // 128 x 128, 256 threads,  64 KiB (2 workgroups per CU: one's epilogue under the other's main loop)
 using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
 
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     if (t < nk) issue(t, t);
   ring_wait<C>((nk - 1 < C::NSTAGE - 2) ? nk - 1 : C::NSTAGE - 2);
   if (C::NSTAGE - 1 < nk) issue(C::NSTAGE - 1, C::NSTAGE - 1);
-  if (C::PIPE) gemm_load_frags<C>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
+  gemm_load_frags<C>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
   int st_cur = 0;
   const bool late = wave >= C::NWAVE / 2;      // the SIMD partner of wave w - NWAVE/2: issues its DMA half a k-tile later
   for (int kt = 0; kt < nk; ++kt) {
@@ -167,28 +165,17 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     const int st_free = st_cur;
     st_cur = st_cur == C::NSTAGE - 1 ? 0 : st_cur + 1;
     const int rem = nk - 2 - kt;
-    if (C::PIPE) {
-      gemm_load_frags<C>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);   // k-step 1 of tile kt: in flight during the MFMAs
-      gemm_mma<C>(acc, f0);                                                      // k-step 0 of tile kt
-      if (kt + 1 < nk) {
-        wait_lgkm0();                                                            // f1 has left LDS: stage st_free is dead for this wave
-        ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);
-        if (!late && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
-        const half_t* An = lds + st_cur * C::STAGE;
-        gemm_load_frags<C>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);     // k-step 0 of tile kt+1: overlaps the MFMAs below
-      }
-      gemm_mma<C>(acc, f1);                                                      // k-step 1 of tile kt
-      if (late && kt + 1 < nk && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
-    } else {
-      gemm_load_frags<C>(f0, As, As + C::BM * GEMM_BK, arow, brow, fchunk);
-      gemm_mma<C>(acc, f0);
-      gemm_load_frags<C>(f0, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
-      gemm_mma<C>(acc, f0);
-      if (kt + 1 < nk) {
-        ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);                 // (the MFMAs above consumed every fragment read)
-        if (kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
-      }
+    gemm_load_frags<C>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);   // k-step 1 of tile kt: in flight during the MFMAs
+    gemm_mma<C>(acc, f0);                                                      // k-step 0 of tile kt
+    if (kt + 1 < nk) {
+      wait_lgkm0();                                                            // f1 has left LDS: stage st_free is dead for this wave
+      ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);
+      if (!late && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
+      const half_t* An = lds + st_cur * C::STAGE;
+      gemm_load_frags<C>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);     // k-step 0 of tile kt+1: overlaps the MFMAs below
     }
+    gemm_mma<C>(acc, f1);                                                      // k-step 1 of tile kt
+    if (late && kt + 1 < nk && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
   }
   // Epilogue through LDS: every wave parks its fp32 accumulator tile in its own slice of the (now idle) ring, then each
   // lane picks up 8 CONSECUTIVE columns of one row.
@@ -262,13 +249,6 @@ struct Gemm8 {
   static constexpr int CT_LD = 64 + 4, EP_MT = 2;
 };
 
-template <int ABL = 0>
-__device__ __forceinline__ void phase_barrier_t(bool wait, bool last) {
-  if (ABL & 4) return;
-  if (!wait) wait_vm_barrier<63>();
-  else if (last) wait_vm_barrier<0>();
-  else wait_vm_barrier<4>();
-}
 __device__ __forceinline__ void phase_barrier(bool wait, bool last) {
   // `wait`: this wave's DMA shares for the next phase's reads must have landed (see RAW above)
   if (!wait) wait_vm_barrier<63>();
@@ -282,7 +262,7 @@ __device__ __forceinline__ void mfma_prio(int on) {
 #endif
 }
 
-template <class Epi, int ABL = 0>
+template <class Epi>
 __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb,
                                                         int M, int N, int K, Epi epi) {
   using C = Gemm8;
@@ -321,12 +301,10 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
   }
   const size_t bhalf = (size_t)32 * ldb;
   auto issue_a = [&](int h, int kt, half_t* stage) {
-    if ((ABL & 1) && kt > 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(gA[h][i] + kt * GEMM_BK, stage + dA[h][i]);
   };
   auto issue_b = [&](int h, int kt, half_t* stage) {
-    if ((ABL & 1) && kt > 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(gB[i] + (h ? bhalf : 0) + kt * GEMM_BK, stage + dB[h][i]);
   };
@@ -338,16 +316,13 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   half8 fa[4][2], fb[2][2][2];       // A: [row tile][k step] of the current half; B: [half][col tile][k step]
   const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15), fchunk = lane >> 4;
-  bool first = true;
   auto read_a = [&](int h, const half_t* stage) {
-    if ((ABL & 2) && !first) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) fa[t][ks] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 16, ks * 4 + fchunk));
   };
   auto read_b = [&](int h, const half_t* stage) {
-    if ((ABL & 2) && !first) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -355,14 +330,14 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
         fb[h][t][ks] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32 + t * 16, ks * 4 + fchunk));
   };
   auto quadrant = [&](int ah, int bh) {
-    if (!(ABL & 8)) mfma_prio(1);
+    mfma_prio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[ah * 4 + mt][bh * 2 + nt] = mfma_16x16x32_f16(fb[bh][nt][ks], fa[mt][ks], acc[ah * 4 + mt][bh * 2 + nt]);
-    if (!(ABL & 8)) mfma_prio(0);
+    mfma_prio(0);
   };
 
   const int nk = K / GEMM_BK;
@@ -377,27 +352,26 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
     // phase 1: quadrant (A0, B0)
     read_a(0, cur); read_b(0, cur);
     if (more) issue_a(0, kt + 1, nxt);
-    phase_barrier_t<ABL>(!lead, !more);
+    phase_barrier(!lead, !more);
     quadrant(0, 0);
-    phase_barrier_t<ABL>(lead, !more);
+    phase_barrier(lead, !more);
     // phase 2: (A0, B1)
     read_b(1, cur);
     if (more) issue_b(0, kt + 1, nxt);
-    phase_barrier_t<ABL>(!lead, !more);
+    phase_barrier(!lead, !more);
     quadrant(0, 1);
-    phase_barrier_t<ABL>(lead, !more);
+    phase_barrier(lead, !more);
     // phase 3: (A1, B1)
     read_a(1, cur);
     if (more) issue_b(1, kt + 1, nxt);
-    phase_barrier_t<ABL>(false, false);
+    phase_barrier(false, false);
     quadrant(1, 1);
-    phase_barrier_t<ABL>(false, false);
+    phase_barrier(false, false);
     // phase 4: (A1, B0) -- nothing to read
     if (more) issue_a(1, kt + 1, nxt);
-    phase_barrier_t<ABL>(!lead, false);
+    phase_barrier(!lead, false);
     quadrant(1, 0);
-    phase_barrier_t<ABL>(lead, false);
-    first = false;
+    phase_barrier(lead, false);
   }
   if (lead) wait_vm_barrier<63>();             // balance the trailing group's extra barrier
   __syncthreads();
@@ -546,11 +520,11 @@ inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int l
   APH_LAUNCH((splitk_reduce_kernel<Epi>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (const float*)sp.ws, splits, M, N, epi);
 }
 
-template <class Epi, int ABL = 0>
+template <class Epi>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, ABL>), Gemm8::SMEM), true);
+  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM), true);
   (void)once;
-  APH_LAUNCH((gemm8_f16_kernel<Epi, ABL>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st,
+  APH_LAUNCH((gemm8_f16_kernel<Epi>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st,
              A, lda, Bt, ldb, M, N, K, epi);
 }
 
@@ -563,9 +537,9 @@ template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                         const SplitKSpace* sp = nullptr) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
-  const int huge_tiles = (N / GemmHuge::BN) * ((M + GemmHuge::BM - 1) / GemmHuge::BM);
+  const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
-  if (N % GemmHuge::BN == 0 && huge_tiles >= 400) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
+  if (N % Gemm8::BN == 0 && huge_tiles >= 400) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {

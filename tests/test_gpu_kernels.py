@@ -72,7 +72,7 @@ def test_gemm_mfma_layout():
 
 
 def test_gemm_every_tile_config():
-    for cfg in (1, 2, 3, 4, 5, 10):
+    for cfg in (1, 2, 4, 10):
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
 
 

@@ -10,7 +10,7 @@ for M in (190, 1200, 2400):
     for K in (768, 2304, 3072):
         A = torch.randn(M, K, device='cuda').half(); B = torch.randn(N, K, device='cuda').half(); C = torch.empty(M, N, device='cuda')
         line = 'M %5d N %5d K %5d:' % (M, N, K)
-        for cfg in (1, 8, 9, 5):
+        for cfg in (1, 8, 9, 10):
             s = torch.cuda.Stream()
             with torch.cuda.stream(s):
                 st = _stream(A)

@@ -9,7 +9,7 @@ for M in (1200, 2400):
         A = torch.randn(M, K, device='cuda').half(); B = torch.randn(N, K, device='cuda').half(); C = torch.empty(M, N, device='cuda')
         line = 'M %5d N %5d K %5d:' % (M, N, K)
         best = None
-        for cfg in (0, 1, 10, 22, 24):
+        for cfg in (0, 1, 2, 4, 10):
             s = torch.cuda.Stream()
             with torch.cuda.stream(s):
                 st = _stream(A)
