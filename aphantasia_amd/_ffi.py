@@ -44,6 +44,7 @@ _PROTOTYPES = {
     'aph_idwt_level_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'aph_sample_fwd': (c_int, [POINTER(SampleGeom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_sample_bwd': (c_int, [POINTER(SampleGeom), c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'aph_frame_affine': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
     'aph_patchify_f16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_unpatchify_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'aph_vit_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),

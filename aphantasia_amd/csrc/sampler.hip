@@ -527,6 +527,45 @@ __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* 
 }
 
 // ---------------------------------------------------------------------------------
+// illustrip's frame_transform (illustrip.py:130-138): T.functional.affine(img, angle, shift, scale, shear, fill=0,
+// BILINEAR) of a whole [C,H,W] image, once per frame.  m = the 2x3 INVERSE affine matrix (host, torchvision's
+// _get_inverse_affine_matrix); grid = [x, y, 1] . (m^T / (0.5 W, 0.5 H)) over the centred base grid, bilinear, zeros
+// padding, ones-mask fill -- the same sampler arithmetic as the per-cut rotation above.
+// ---------------------------------------------------------------------------------
+struct Affine6 { float m[6]; };
+
+__global__ void frame_affine_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, Affine6 a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const float bx = -(float)W * 0.5f + 0.5f + (float)x, by = -(float)H * 0.5f + 0.5f + (float)y;
+  const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+  const float gx = bx * (a.m[0] / hw) + by * (a.m[1] / hw) + (a.m[2] / hw);
+  const float gy = bx * (a.m[3] / hh) + by * (a.m[4] / hh) + (a.m[5] / hh);
+  const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+  float w[4];
+  int off[4];
+  float mask = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+    const bool in = xx >= 0 && xx < W && yy >= 0 && yy < H;
+    w[k] = in ? ((k & 1) ? wx1 : wx0) * ((k >> 1) ? wy1 : wy0) : 0.f;
+    off[k] = in ? yy * W + xx : 0;
+    mask += w[k];
+  }
+  for (int c = 0; c < C; ++c) {
+    const float* pl = src + (size_t)c * H * W;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += w[k] * pl[off[k]];
+    dst[((size_t)c * H + y) * W + x] = v * mask;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // layout conversion for caller-made batches (model.encode_image(x) on an NCHW tensor)
 // ---------------------------------------------------------------------------------
 __global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int S, int R, int p) {
@@ -631,6 +670,18 @@ int aph_unpatchify_f32(const float* g, int S, int R, int patch, float gscale, fl
   if (!g || !out || S < 1 || R < 1 || patch < 1 || R % patch) return aph_fail(APH_ERR_ARG, "aph_unpatchify_f32: bad argument");
   APH_LAUNCH(unpatchify_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, g, out, S, R, patch, gscale);
   return aph_check_launch("aph_unpatchify_f32");
+  APH_CATCH
+}
+
+// illustrip.py:130-138 frame_transform: d_dst [C,H,W] = affine warp of d_src [C,H,W] (d_dst != d_src).
+// inv_matrix6: row-major 2x3 inverse affine matrix as torchvision's _get_inverse_affine_matrix returns it.
+int aph_frame_affine(const float* d_src, int C, int H, int W, const float* inv_matrix6, float* d_dst, void* stream_) {
+  APH_TRY
+  if (!d_src || !d_dst || !inv_matrix6 || d_src == d_dst || C < 1 || H < 1 || W < 1) return aph_fail(APH_ERR_ARG, "aph_frame_affine: bad argument");
+  Affine6 a;
+  for (int i = 0; i < 6; ++i) a.m[i] = inv_matrix6[i];
+  APH_LAUNCH(frame_affine_kernel, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream_, d_src, d_dst, C, H, W, a);
+  return aph_check_launch("aph_frame_affine");
   APH_CATCH
 }
 

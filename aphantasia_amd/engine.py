@@ -148,6 +148,20 @@ class Engine:
         self.dcoef = torch.tensor(self.coef, dtype=torch.float32, device=self.dev)
         self.hcoef = _ffi.floats(self.coef)
 
+    def reset_params(self, new_params, keep_optimizer_state=False):
+        """illustrip's per-frame re-parameterisation (illustrip.py:390,411-423) without re-creating anything: the new frame's
+        parameters are copied INTO the existing leaf (same shape), the hipGraphs stay valid, and the Adam state is zeroed like a
+        fresh torch.optim instance unless `keep_optimizer_state` (`--smooth`: optimizer.load_state_dict(opt_state))."""
+        if tuple(new_params.shape) != tuple(self.params.shape) and new_params.numel() != self.params.numel():
+            raise ValueError('reset_params: shape %s does not match %s' % (tuple(new_params.shape), tuple(self.params.shape)))
+        with torch.no_grad():
+            self.params.copy_(new_params.reshape(self.params.shape))
+            if not keep_optimizer_state:
+                for t in (self.m, self.v, self.vmax):
+                    if t is not None:
+                        t.zero_()
+                self._state['step'][0] = 0
+
     def set_prev_enc(self, enc_rows=None):
         """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
         target of the next step with coefficient +expand (clip_fft.py:276-280: `loss += a.expand * sim_func(out_enc, prev_enc)`)."""

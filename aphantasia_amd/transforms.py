@@ -162,3 +162,43 @@ def draw_fast_bulk(S, size, rng):
     rot = np.radians(ang)
     t[:, 13], t[:, 14], t[:, 15] = np.cos(rot), np.sin(rot), 1.0
     return t
+
+
+# ----------------------------------------------------------------------------- illustrip's per-frame warp
+def inverse_affine_matrix(angle, translate, scale, shear):
+    """torchvision's _get_inverse_affine_matrix(center=[0, 0], angle, translate, scale, shear) -- the matrix
+    T.functional.affine builds for tensors (origin at the image centre).  shear: degrees or (sx, sy)."""
+    if isinstance(shear, (int, float)):
+        shear = [float(shear), 0.0]
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    tx, ty = float(translate[0]), float(translate[1])
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [v / scale for v in (d, -b, 0.0, -c, a, 0.0)]
+    m[2] += m[0] * (-tx) + m[1] * (-ty)
+    m[5] += m[3] * (-tx) + m[4] * (-ty)
+    return m
+
+
+def frame_transform(img, size, angle, shift, scale, shear, lib=None):
+    """illustrip.py:130-138: T.functional.affine(img, angle, tuple(shift), scale, shear, fill=0, BILINEAR) followed by
+    center_crop(size) (which also zero-pads on torch >= 1.8).  img: [1,C,H,W] f32 on the GPU; one HIP launch."""
+    from . import ops
+    x = img.detach().reshape(-1, img.shape[-2], img.shape[-1]).float().contiguous()
+    C, H, W = x.shape
+    out = torch.empty_like(x)
+    L = ops._L(lib, x)
+    L.call('aph_frame_affine', ops.ptr(x), C, H, W, _ffi.floats(inverse_affine_matrix(angle, shift, scale, shear)), ops.ptr(out), ops._stream(x))
+    out = out.reshape(1, C, H, W)
+    th, tw = int(size[0]), int(size[1])
+    if (th, tw) != (H, W):                      # torchvision center_crop: pad symmetric zeros if smaller, then crop
+        ph, pw = max(th - H, 0), max(tw - W, 0)
+        if ph or pw:
+            out = torch.nn.functional.pad(out, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+        H2, W2 = out.shape[-2:]
+        top, left = int(round((H2 - th) / 2.0)), int(round((W2 - tw) / 2.0))
+        out = out[..., top:top + th, left:left + tw].contiguous()
+    return out

@@ -112,6 +112,10 @@ int aph_sample_fwd(const aph_sample_geom* g, const float* d_rgb, const int32_t* 
  * Writes (does not accumulate) d_rgb_grad [3,H,W]. */
 int aph_sample_bwd(const aph_sample_geom* g, const void* d_out_grad, float gscale, const int32_t* d_table,
                    const float* d_aug, float* d_tmp, float* d_rgb_grad, int out_mode, void* stream);
+/* illustrip.py:130-138 frame_transform = T.functional.affine(img, angle, shift, scale, shear, fill=0, BILINEAR) of a whole
+ * [C,H,W] image (once per frame).  h_inv_matrix6: HOST pointer, row-major 2x3 inverse affine matrix (torchvision's
+ * _get_inverse_affine_matrix with the image centre as origin).  d_dst must not alias d_src. */
+int aph_frame_affine(const float* d_src, int C, int H, int W, const float* h_inv_matrix6, float* d_dst, void* stream);
 /* NCHW f32 [S,3,R,R] <-> patch-major (entry of model.encode_image for a caller-made batch) */
 int aph_patchify_f16(const float* d_nchw, int S, int R, int patch, void* d_patches_f16, void* stream);
 int aph_unpatchify_f32(const float* d_patch_grad, int S, int R, int patch, float gscale, float* d_nchw_grad, void* stream);

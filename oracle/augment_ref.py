@@ -116,6 +116,40 @@ def rotate(img, angle):
     return _apply_grid(img, grid)
 
 
+def inverse_affine_matrix(angle, translate, scale, shear):
+    """torchvision.transforms.functional._get_inverse_affine_matrix(center=[0,0], ..., inverted=True) as called by
+    T.functional.affine on tensors (center is the image centre in the tensor code path).  shear: number or (sx, sy)."""
+    if isinstance(shear, (int, float)):
+        shear = [float(shear), 0.0]
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    tx, ty = float(translate[0]), float(translate[1])
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [d, -b, 0.0, -c, a, 0.0]
+    m = [x / scale for x in m]
+    m[2] += m[0] * (-tx) + m[1] * (-ty)
+    m[5] += m[3] * (-tx) + m[4] * (-ty)
+    return m
+
+
+def affine(img, angle, translate, scale, shear):
+    """T.functional.affine(img, angle, translate, scale, shear, fill=0, BILINEAR) on an NCHW tensor
+    (illustrip.py:130-138 frame_transform; the same-size center_crop that follows is the identity)."""
+    oh, ow = img.shape[-2:]
+    theta = torch.tensor(inverse_affine_matrix(angle, translate, scale, shear), dtype=img.dtype).reshape(1, 2, 3)
+    d = 0.5
+    base = torch.empty(1, oh, ow, 3, dtype=img.dtype)
+    base[..., 0].copy_(torch.linspace(-ow * 0.5 + d, ow * 0.5 + d - 1, steps=ow))
+    base[..., 1].copy_(torch.linspace(-oh * 0.5 + d, oh * 0.5 + d - 1, steps=oh).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rt = theta.transpose(1, 2) / torch.tensor([0.5 * ow, 0.5 * oh], dtype=img.dtype)
+    grid = base.view(1, oh * ow, 3).bmm(rt).view(1, oh, ow, 2).expand(img.shape[0], oh, ow, 2)
+    return _apply_grid(img, grid)
+
+
 def erase(img, rect):
     i, j, h, w = rect
     img = img.clone()

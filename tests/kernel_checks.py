@@ -283,3 +283,20 @@ def check_rgb_sharp(lib, dev):
         assert abs(loss.item() + 0.7 * want.item()) < 1e-6
         err = (grad.cpu() + 0.7 * x.grad.reshape(3, h, w)).abs().max().item()
         assert err < 1e-5 * x.grad.abs().max().item(), err
+
+
+def check_frame_affine(lib, dev):
+    """aph_frame_affine vs the oracle's restatement of T.functional.affine (bilinear, zero fill, ones-mask)"""
+    from aphantasia_amd import transforms
+    from oracle import augment_ref
+    g = torch.Generator().manual_seed(8)
+    for (h, w, args) in ((37, 53, (7.5, (3, -2), 1.1, 4.0)), (48, 80, (0.0, (0, 1), 1.02, 0.0)), (40, 64, (-30.0, (-5, 6), 0.8, (10.0, -3.0)))):
+        x = torch.rand(1, 3, h, w, generator=g)
+        want = augment_ref.affine(x, *args)
+        got = transforms.frame_transform(x.to(dev), (h, w), args[0], args[1], args[2], args[3], lib=lib).cpu()
+        err = (got - want).abs().max().item()
+        assert err < 2e-5, (err, args)
+    x = torch.rand(1, 3, 20, 30, generator=g)
+    got = transforms.frame_transform(x.to(dev), (24, 26), 0.0, (0, 0), 1.0, 0.0, lib=lib).cpu()      # identity warp, then pad rows / crop cols
+    assert got.shape == (1, 3, 24, 26)
+    assert torch.allclose(got[..., 2:22, :], x[..., :, 2:28], atol=1e-5) and float(got[..., :2, :].abs().max()) == 0.0

@@ -97,3 +97,7 @@ def test_rgb_priors(emu):
 
 def test_rgb_sharp(emu):
     K.check_rgb_sharp(emu, 'cpu')
+
+
+def test_frame_affine(emu):
+    K.check_frame_affine(emu, 'cpu')

@@ -119,3 +119,7 @@ def test_rgb_priors():
 
 def test_rgb_sharp():
     K.check_rgb_sharp(None, DEV)
+
+
+def test_frame_affine():
+    K.check_frame_affine(None, DEV)

@@ -357,3 +357,42 @@ def test_f16_patch_gradient_option_is_close(model):
     assert outs[0][0] == outs[1][0]
     d = (outs[0][1] - outs[1][1]).abs().max().item()
     assert d < 2e-3 * outs[0][1].abs().max().item(), d
+
+
+@pytest.mark.parametrize('gen', ['RGB', 'FFT'])
+def test_illustrip_frame_loop_reparameterisation(model, gen):
+    """illustrip.py:381-423: per frame, warp the current image (frame_transform), re-create the parameters from it and
+    restart the optimiser.  Engine.reset_params does that in place (no re-allocation, hipGraphs stay valid) and must be
+    indistinguishable from building a fresh engine on the warped parameters."""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    h, w, S = 192, 256, 6
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    kw = dict(sim='mix', transform=transforms.transforms_fast, macro=0.4, rng='reference')
+    if gen == 'RGB':
+        kw.update(param_kind='pixel', rgb_priors=True)
+    seed_all(0)
+    p0 = (torch.randn(1, 3, h, w) * 0.3 if gen == 'RGB' else 0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+    eng = Engine(p0.clone(), h, w, model, S, [(target, -1.0)], **kw)
+
+    def warp(params):
+        if gen == 'RGB':
+            return transforms.frame_transform(params, (h, w), 2.0, (3, -1), 1.03, 1.0)
+        img = torch.fft.irfftn(torch.view_as_complex(params), s=(h, w), norm='ortho')                  # illustrip.py:401-403
+        img = transforms.frame_transform(img, (h, w), 2.0, (3, -1), 1.03, 1.0)
+        return torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho')).contiguous()   # :407-408
+
+    for frame in range(3):
+        for i in range(4):                       # enough steps for the hipGraph to be captured and replayed
+            seed_all(100 * frame + i)
+            l_last = float(eng.step())
+        assert np.isfinite(l_last)
+        new = warp(eng.params.detach())
+        eng.reset_params(new)
+        assert torch.equal(eng.params.reshape(-1), new.reshape(-1)) and eng.step_count == 0
+        fresh = Engine(new.clone(), h, w, model, S, [(target, -1.0)], use_graph=False, **kw)
+        seed_all(999); a = float(eng.step())
+        seed_all(999); b = float(fresh.step())
+        assert a == b, (frame, a, b)
+        assert torch.equal(eng.params, fresh.params)
+        eng.reset_params(new)                    # continue the loop from the warped frame
