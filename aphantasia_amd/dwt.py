@@ -37,6 +37,40 @@ def dwt_scale_from_sizes(sizes, sharp):
     return [((h0 * w0) / (h * w)) ** (1. - sharp) for (h, w) in sizes]
 
 
+def dwt_forward_host(x, wave, J=None):
+    """pytorch_wavelets.DWTForward(J, wave, mode='symmetric') on the host (one-off: resuming the wavelet parameters from an
+    image, image.py:82-94).  x: [N,C,H,W] tensor -> (yl [N,C,h,w], [yh_j [N,C,3,h_j,w_j]] finest first, bands (LH, HL, HH) =
+    pywt's (cH, cV, cD)).  Per axis: half-sample symmetric extension, correlation with the reversed decomposition filters
+    (dec_lo = rec_lo[::-1]; dec_hi = QMF), keep every second sample: c[i] = sum_j dec[j] x_ext[2 i + 1 - j]."""
+    import numpy as np
+    rec_lo = np.asarray(REC_LO[wave], dtype=np.float64)
+    L = len(rec_lo)
+    dec_lo = rec_lo[::-1].copy()
+    rec_hi = np.array([(-1) ** k * rec_lo[L - 1 - k] for k in range(L)])
+    dec_hi = rec_hi[::-1].copy()
+
+    def afb(a, axis):
+        a = np.moveaxis(a, axis, -1)
+        n = a.shape[-1]
+        out = (n + L - 1) // 2
+        ext = np.pad(a, [(0, 0)] * (a.ndim - 1) + [(L - 1, L - 1)], mode='symmetric')
+        idx = (2 * np.arange(out)[:, None] + 1 - np.arange(L)[None, :]) + (L - 1)          # [out, L] positions in ext
+        g = ext[..., idx]                                                                  # [..., out, L]
+        lo, hi = (g * dec_lo).sum(-1), (g * dec_hi).sum(-1)
+        return np.moveaxis(lo, -1, axis), np.moveaxis(hi, -1, axis)
+
+    a = x.detach().cpu().double().numpy()
+    J = max_level(a.shape[-2], a.shape[-1]) if J is None else J
+    yh = []
+    for _ in range(J):
+        lo_w, hi_w = afb(a, 3)                      # along width
+        ll, lh = afb(lo_w, 2)                       # then along height: (low-w, low-h), (low-w, high-h) = cH
+        hl, hh = afb(hi_w, 2)                       # (high-w, low-h) = cV, (high-w, high-h) = cD
+        yh.append(torch.from_numpy(np.stack([lh, hl, hh], axis=2)).float())
+        a = ll
+    return torch.from_numpy(a).float(), yh
+
+
 class DWTSynth:
     """Coefficient storage + the level-by-level inverse transform and its adjoint."""
 

@@ -329,29 +329,46 @@ class DWTImage:
         return _SynthDWT.apply(self, float(contrast), cc, decorrelate, True, *self.Ys)
 
 
+def img2dwt(img_in, wave='coif2', sharp=0.3, colors=1.):
+    """image.py:82-94: un_rgb -> DWTForward(J = max level, wave, 'symmetric') -> detail levels divided by dwt_scale.
+    Returns the `Ys` list [Yl, Yh finest first ...] (host tensors)."""
+    from .dwt import dwt_forward_host, dwt_scale_from_sizes
+    image_t = un_rgb(img_in, colors=colors)
+    yl, yh = dwt_forward_host(image_t, wave)
+    scale = dwt_scale_from_sizes([tuple(y.shape[-2:]) for y in yh], sharp)
+    return [yl] + [y / scale[i] for i, y in enumerate(yh)]
+
+
 def dwt_image(shape, wave='coif2', sharp=0.3, colors=1., resume=None):
     """image.py:61-71 -> (Ys, image_f, size).  Random init draws randn per tensor on the CPU generator in the
-    reference's order (Yl, then detail levels finest first; image.py:41-42).  `resume`: list of tensors or a .pt file."""
+    reference's order (Yl, then detail levels finest first; image.py:41-42).  `resume`: list of tensors, a .pt file, or an
+    image file (img2dwt; the image then sets the size)."""
     h, w = shape[2:]
+    size = None
+    if isinstance(resume, str):
+        if not os.path.isfile(resume):
+            print(' Snapshot not found:', resume)
+            exit()
+        if os.path.splitext(resume)[1].lower()[1:] in ['jpg', 'png', 'tif', 'bmp']:      # image.py:43-50: the image sets the size
+            from .utils import img_read
+            img_in = img_read(resume)
+            resume = img2dwt(img_in, wave, sharp, colors)
+            size = img_in.shape[:2]
+            h, w = int(size[0]), int(size[1])
+        else:
+            resume = torch.load(resume)
     gen = DWTImage(h, w, wave, sharp, _device())
     views = gen.synth.views(gen.flat)
     if resume is None:
         init = [torch.randn(*v.shape) for v in views]
     else:
-        if isinstance(resume, str):
-            if not os.path.isfile(resume):
-                print(' Snapshot not found:', resume)
-                exit()
-            if os.path.splitext(resume)[1].lower()[1:] in ['jpg', 'png', 'tif', 'bmp']:
-                raise NotImplementedError('resuming the DWT parameters from an image file (img2dwt) is not implemented')
-            resume = torch.load(resume)
         init = [y.detach().float() for y in resume]
         if [tuple(y.shape) for y in init] != [tuple(v.shape) for v in views]:
             raise ValueError('snapshot coefficient shapes do not match a %dx%d %s transform' % (w, h, wave))
     for v, y in zip(views, init):
         v.copy_(y)
     gen.Ys = [v.requires_grad_(True) for v in views]
-    return gen.Ys, gen, None
+    return gen.Ys, gen, size
 
 
 def to_valid_rgb(image_f, colors=1., decorrelate=True):

@@ -2,6 +2,7 @@
 reference's notebook pins; the main interpreter has no pywt).  Two jobs:
   python3.9 oracle/pywt_dump.py filters OUT.py      -> reconstruction filter taps for the wavelets the CLI accepts
   python3.9 oracle/pywt_dump.py waverec2 IN.npz OUT.npy -> pywt.waverec2 of dumped coefficients (DWT oracle pin)
+  python3.9 oracle/pywt_dump.py wavedec2 IN.npz OUT.npz -> pywt.wavedec2 of a dumped image (forward-transform pin)
 """
 import sys
 import numpy as np
@@ -33,8 +34,21 @@ def waverec2(inp, out):
     np.save(out, pywt.waverec2(coeffs, str(d['wave']), 'symmetric'))
 
 
+def wavedec2(inp, out):
+    """forward transform pin: IN.npz {x [H,W], wave, J} -> OUT.npz {yl, yh0.. (finest first, (cH,cV,cD) stacked)}"""
+    d = np.load(inp)
+    J = int(d['J'])
+    c = pywt.wavedec2(d['x'], str(d['wave']), 'symmetric', level=J)
+    res = {'yl': c[0]}
+    for j in range(J):                      # c[1] is the coarsest
+        res['yh%d' % (J - 1 - j)] = np.stack(c[1 + j])
+    np.savez(out, **res)
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'filters':
         filters(sys.argv[2])
+    elif sys.argv[1] == 'wavedec2':
+        wavedec2(sys.argv[2], sys.argv[3])
     else:
         waverec2(sys.argv[2], sys.argv[3])

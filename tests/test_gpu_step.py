@@ -242,6 +242,9 @@ def test_cli_resume_from_image_and_pt(tmp_path):
     assert len(frames) == 3
     clip_fft.main(['-t', 'cat', '-nv', '--seed', '0', '--steps', '2', '--samples', '12', '--size', '128-96', '--resume', os.path.join(out, pts[0]),
                    '--out_dir', os.path.join(tmp_path, 'out2'), '--no_save'])
+    # wavelet parameters from the same image (img2dwt): the first synthesised frame reproduces the image's colours roughly
+    clip_fft.main(['-t', 'cat', '-nv', '--seed', '0', '--steps', '2', '--samples', '12', '--dwt', '-w', 'db3', '--resume', jpg,
+                   '--out_dir', os.path.join(tmp_path, 'out3'), '--no_save'])
 
 
 def test_sharp_and_expand_terms_vs_autograd_api(model):
