@@ -54,6 +54,8 @@ class Engine:
         self.size = size or self.visual.input_resolution
         self.patch = self.visual.patch_size
         self.S = int(samples)
+        if self.S < 1:
+            raise ValueError('Engine: samples = %d; at least one cut is needed (upstream: torch.cat of an empty list, utils.py:253)' % self.S)
         self.rank, self.world, self.pg = rank, world, process_group
         self.lo, self.hi = shard_range(self.S, rank, world)
         self.S_loc = self.hi - self.lo

@@ -110,6 +110,14 @@ def derate_samples(a):
     return s
 
 
+def check_samples(n):
+    """upstream, `--samples 1` with the default `-tf fast` derates to int(1 * 0.95) = 0 cuts and dies in torch.cat([])
+    (clip_fft.py:169, utils.py:253); say so instead"""
+    if n < 1:
+        raise SystemExit(' --samples derates to %d cuts for this model / transform (clip_fft.py:125-169): nothing to optimise; '
+                         'raise --samples or use -tf none' % n)
+
+
 class FrameWriter:
     """Background JPEG writers: the reference converts and encodes every frame synchronously inside the hot loop
     (clip_fft.py:297-306, utils.py:94-100).  Here the loop only enqueues a device-side uint8 conversion and an async
@@ -186,6 +194,7 @@ def main(argv=None):
         a.modsize = model_clip.visual.input_resolution
         if a.verbose is True: print(' using model', a.model)
         a.samples = derate_samples(a)
+        check_samples(a.samples)
         if a.dualmod is not None:
             model_clip2, _ = aclip.load('ViT-B/16', weights=a.clip_weights2)
             dualmod_nums = list(range(a.steps))[a.dualmod::a.dualmod]
