@@ -492,7 +492,7 @@ __global__ void rgb_sharp_apply_kernel(const float* __restrict__ rgb, int H, int
 using namespace aph;
 
 struct aph_synth_plan {
-  int C, H, W, Wc, TC;
+  int C, H, W, Wc, TC, col_threads = 1024;   // column pass: 8 columns x 1024 threads measured best at 720p (95 vs 122 us per synth fwd+bwd)
   Fft1D ph, pw;
   float2* twH = nullptr;
   float2* twW = nullptr;
@@ -580,7 +580,7 @@ int aph_synth_fft_fwd(aph_synth_plan* p, const float* params, const float* scale
   if (!p || !params || !scale || !raw || !rgb) return aph_fail(APH_ERR_ARG, "aph_synth_fft_fwd: null argument");
   hipStream_t st = (hipStream_t)stream_;
   const int G = p->C * p->Wc;
-  APH_LAUNCH(fft_col_synth_kernel, dim3((G + p->TC - 1) / p->TC), dim3(256), sizeof(float2) * 2 * p->TC * p->H, st,
+  APH_LAUNCH(fft_col_synth_kernel, dim3((G + p->TC - 1) / p->TC), dim3(p->col_threads), sizeof(float2) * 2 * p->TC * p->H, st,
              (const float2*)params, scale, shift, p->tmp, p->ph, (const float2*)p->twH, p->C, p->H, p->Wc, p->TC);
   const float norm = (float)(1.0 / sqrt((double)p->H * (double)p->W));
   APH_LAUNCH(fft_row_synth_kernel, dim3(p->nrow_blocks), dim3(256), sizeof(float2) * 2 * p->W, st,
@@ -610,7 +610,7 @@ int aph_synth_fft_bwd(aph_synth_plan* p, const float* d_rgb, float gscale, const
   APH_LAUNCH(fft_row_adjoint_kernel, dim3(p->nrow_blocks), dim3(256), sizeof(float2) * 2 * p->W, st, (const float*)p->dn, raw,
              (const float*)p->bstats, p->tmp, p->pw, (const float2*)p->twW, p->H, p->W, p->Wc, norm);
   const int G = p->C * p->Wc;
-  APH_LAUNCH(fft_col_adjoint_kernel, dim3((G + p->TC - 1) / p->TC), dim3(256), sizeof(float2) * 2 * p->TC * p->H, st,
+  APH_LAUNCH(fft_col_adjoint_kernel, dim3((G + p->TC - 1) / p->TC), dim3(p->col_threads), sizeof(float2) * 2 * p->TC * p->H, st,
              (const float2*)p->tmp, scale, (float2*)grad_params, p->ph, (const float2*)p->twH, p->C, p->H, p->Wc, p->TC);
   return aph_check_launch("aph_synth_fft_bwd");
   APH_CATCH

@@ -156,9 +156,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (e < E) {
     int d = d0;
-    for (; d + 8 <= d0 + dh; d += 8) {
+    for (; d + 16 <= d0 + dh; d += 16) {           // 16 independent loads in flight per thread: the loop is L2-latency bound
+      float w[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += y[d + u] * proj[(size_t)(d + u) * E + e];
+      for (int u = 0; u < 16; ++u) w[u] = proj[(size_t)(d + u) * E + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u & 7] += y[d + u] * w[u];
     }
     for (; d < d0 + dh; ++d) acc[0] += y[d] * proj[(size_t)d * E + e];
   }
@@ -185,9 +188,12 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict_
   const float rstd = rsqrtf(block_sum(c * c, red) / D + kLnEps);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int e = 0;
-  for (; e + 8 <= E; e += 8) {
+  for (; e + 16 <= E; e += 16) {                   // 16 independent loads in flight per thread (L2-latency bound loop)
+    float w[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += ge[e + u] * projT[(size_t)(e + u) * D + d];
+    for (int u = 0; u < 16; ++u) w[u] = projT[(size_t)(e + u) * D + d];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u & 7] += ge[e + u] * w[u];
   }
   for (; e < E; ++e) acc[0] += ge[e] * projT[(size_t)e * D + d];
   const float g = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) * gamma[d];
