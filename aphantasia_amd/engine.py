@@ -61,6 +61,12 @@ class Engine:
         self.S_loc = self.hi - self.lo
         self.sim = sim
         self.rng_mode = rng
+        # hipGraph replay is a single-rank optimisation (it only saves host time; on the 128-core GPU box eager launches
+        # measure the same step time at every shard size).  Multi-rank runs launch eagerly: graph replays next to a
+        # collective backend's streams gave NaN / wrong gradients after the mid-run barrier + device synchronize that
+        # bench.py performs (reproduced with gloo on one device and with RCCL at world size 1; eager launches never did).
+        if world > 1:
+            use_graph = False
         self.use_graph, self._graphs, self._calls = use_graph, None, 0
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
@@ -326,10 +332,9 @@ class Engine:
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
         if self.world > 1 and self.params.is_cuda:
-            # Multi-rank: never launch on the legacy default (NULL) stream.  hipGraph replays on the NULL stream next to a
-            # collective backend's own streams (event waits in both directions) gave NaN gradients after a mid-run device
-            # synchronize (measured with two ranks over gloo; gone on a dedicated stream).  The caller's stream is fenced
-            # on entry and exit, so results are visible to it as before.
+            # Multi-rank: run the step on a dedicated stream rather than the legacy default (NULL) stream, whose implicit
+            # synchronisation with other streams interacts with the collective backend's own streams.  The caller's
+            # stream is fenced on entry and exit, so results are visible to it as before.
             if self._own_stream is None:
                 self._own_stream = torch.cuda.Stream(device=self.dev)
             cur = torch.cuda.current_stream(self.dev)

@@ -40,6 +40,7 @@ def parse():
     p.add_argument('--transform', default='fast', choices=['fast', 'none'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     return p.parse_args()
 
 
@@ -105,7 +106,7 @@ def main():
     params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
     target = torch.randn(1, model.visual.output_dim, generator=torch.Generator().manual_seed(2))
     eng = Engine(params, h, w, model, S, [(target, -1.0)], sim='mix', transform=trf, macro=0.4,
-                 rank=rank, world=world, process_group=pg)
+                 rank=rank, world=world, process_group=pg, use_graph=not a.no_graph)
 
     def sync():
         if world > 1:
