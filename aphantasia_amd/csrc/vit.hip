@@ -306,8 +306,9 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
-  (void)hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st);       // only the class rows carry gradient out of the head
-  (void)hipMemsetAsync(v->dx16, 0, sizeof(half_t) * (size_t)M * D, st);
+  // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
+  // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
+  (void)hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st);
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   if (half == 0 && e < E) enc[(size_t)s * E + e] = part[threadIdx.x] + part[threadIdx.x + 128];
 }
 
-// head backward: genc [S,E] -> the class-token rows of dx (fp32) and dx16; every other row of dx / dx16 must have
-// been zeroed by the caller (only the class token reaches the head).  projT = proj transposed [E, D].
+// head backward: genc [S,E] -> the class-token rows of dx (fp32) and dx16; every other row of dx must have been zeroed
+// by the caller (only the class token reaches the head; the other rows of dx16 are not read before they are rewritten).  projT = proj transposed [E, D].
 // One workgroup per image, one thread per feature d (blockDim.x == D <= 1024).
 __global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict__ genc, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ projT,
