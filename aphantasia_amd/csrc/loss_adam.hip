@@ -138,8 +138,22 @@ __global__ void loss_reduce_kernel(const float* __restrict__ partial, int S, flo
 // Adam / AdamW (torch.optim semantics, single tensor).  hyper = device floats so a captured graph
 // can be replayed with new step / lr:  {lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt(bias_corr2), gradscale}
 // ---------------------------------------------------------------------------------
+// guard[0] = running count of skipped (overflowed) steps, guard[1] = "this step's gradient has a non-finite element"
+__global__ void grad_guard_kernel(const float* __restrict__ g, size_t n, int* __restrict__ guard) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = g[i];
+    bad |= !(fabsf(x) <= 3.0e38f);             // false for NaN and +-inf
+  }
+  if (bad) guard[1] = 1;                         // every writer stores the same value
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            float* __restrict__ vmax, const float* __restrict__ hyper, int decoupled, size_t n) {
+                            float* __restrict__ vmax, const float* __restrict__ hyper, int decoupled, size_t n, int* __restrict__ guard) {
+  if (guard && guard[1]) {                       // overflowed step: leave parameters and moments untouched
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) guard[0] += 1;
+    return;
+  }
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], sbc2 = hyper[6],
               gs = hyper[7];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -202,8 +216,24 @@ int aph_adam_step(float* d_p, const float* d_g, float* d_m, float* d_v, float* d
                   size_t n, void* stream_) {
   APH_TRY
   if (!d_p || !d_g || !d_v || !d_hyper) return aph_fail(APH_ERR_ARG, "aph_adam_step: null argument");
-  APH_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, d_p, d_g, d_m, d_v, d_vmax, d_hyper, decoupled_wd, n);
+  APH_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, d_p, d_g, d_m, d_v, d_vmax, d_hyper, decoupled_wd, n, (int*)nullptr);
   return aph_check_launch("aph_adam_step");
+  APH_CATCH
+}
+
+// The same update behind an overflow guard (mixed-precision training practice; the reference runs CLIP in fp16 without
+// one): if the gradient holds a NaN / inf -- an fp16 overflow somewhere in the loss-scaled backward -- the step is skipped
+// and d_guard[0] (int, running count of skipped steps) is incremented; d_guard[1] is scratch.  d_guard: 2 ints, zeroed once
+// by the caller, who lowers its loss scale when the count moves.
+int aph_adam_step_guarded(float* d_p, const float* d_g, float* d_m, float* d_v, float* d_vmax, const float* d_hyper, int decoupled_wd,
+                          size_t n, int* d_guard, void* stream_) {
+  APH_TRY
+  if (!d_p || !d_g || !d_v || !d_hyper || !d_guard) return aph_fail(APH_ERR_ARG, "aph_adam_step_guarded: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  (void)hipMemsetAsync(d_guard + 1, 0, sizeof(int), st);
+  APH_LAUNCH(grad_guard_kernel, dim3(512), dim3(256), 0, st, d_g, n, d_guard);
+  APH_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, st, d_p, d_g, d_m, d_v, d_vmax, d_hyper, decoupled_wd, n, d_guard);
+  return aph_check_launch("aph_adam_step_guarded");
   APH_CATCH
 }
 

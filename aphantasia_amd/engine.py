@@ -37,7 +37,7 @@ class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False):
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -71,6 +71,10 @@ class Engine:
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
         self.sharp, self.expand = float(sharp), float(expand)       # clip_fft.py:269-270, :276-280
+        # static loss scale of the fp16 backward with back-off: an overflowed step (NaN / inf gradient) is skipped on the
+        # device (aph_adam_step_guarded); the host looks at the skip counter every GUARD_EVERY steps and halves the scale
+        self.loss_scale = float(LOSS_SCALE if loss_scale is None else loss_scale)
+        self._guard_seen, self._guard_host, self._guard_ev = 0, None, None
         self.enforce = float(enforce)                               # clip_fft.py:271-275
         self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
@@ -118,6 +122,7 @@ class Engine:
         self.prior_ws = torch.empty(int(self.lib.cdll.aph_rgb_priors_ws_bytes()) // 8, device=self.dev, dtype=torch.float64)
         self.ws = torch.empty(Sl * (len(targets) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
+        self.guard = torch.zeros(2, dtype=torch.int32, device=self.dev)      # [skipped-step count, scratch]
         self._own_stream = None
         self._stage, self._stage_i = None, 0       # pinned host ring for the per-step H2D refreshes (built lazily, GPU only)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
@@ -219,7 +224,7 @@ class Engine:
                    ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
             self.visual._forward_patches(self.patches, Sl, self.enc)
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
-                   len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), LOSS_SCALE, ops.ptr(self.ws),
+                   len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), self.loss_scale, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
             if self.enforce != 0:
                 self._enqueue_enforce(L, st, Sl)
@@ -252,8 +257,8 @@ class Engine:
         """(out_scale of the ViT backward, gscale of the sampler adjoint, gradient layout): the f16 patch gradient keeps the
         loss scale (range) and the sampler adjoint removes it"""
         if self.grad_f16:
-            return 1.0, 1.0 / LOSS_SCALE, _ffi.APH_GRAD_PATCH_F16
-        return 1.0 / LOSS_SCALE, 1.0, _ffi.APH_OUT_PATCH_F16
+            return 1.0, 1.0 / self.loss_scale, _ffi.APH_GRAD_PATCH_F16
+        return 1.0 / self.loss_scale, 1.0, _ffi.APH_OUT_PATCH_F16
 
     def _enqueue_enforce(self, L, st, Sl):
         """--enforce (clip_fft.py:271-275): `loss -= a.enforce * sim_func(out_enc, out_enc2)` with out_enc2 from a second,
@@ -266,7 +271,7 @@ class Engine:
 
         def pair_term(enc, other, loss, genc):      # value + d/d enc of -enforce * sim(enc[s], other[s]) (mean over the GLOBAL S cuts)
             L.call('aph_sim_loss', ops.ptr(enc), Sl, D, ops.ptr(other), ops.ptr(self.enf_coef), hc, 1, 0, Sl, 0, code, float(self.S),
-                   LOSS_SCALE, ops.ptr(self.ws2), ops.ptr(loss), ops.ptr(genc), st)
+                   self.loss_scale, ops.ptr(self.ws2), ops.ptr(loss), ops.ptr(genc), st)
         L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table2), ops.ptr(self.aug2), ops.ptr(self.tmp),
                ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
         self.visual._forward_patches(self.patches, Sl, self.enc2)
@@ -313,9 +318,34 @@ class Engine:
         slot['ev'] = torch.cuda.Event()
         slot['ev'].record()
 
+    GUARD_EVERY = 16
+
     def _enqueue_adam(self):
-        self.lib.call('aph_adam_step', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
-                      ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), ops._stream(self.params))
+        self.lib.call('aph_adam_step_guarded', ops.ptr(self.params), ops.ptr(self.grad), ops.ptr(self.m), ops.ptr(self.v), ops.ptr(self.vmax),
+                      ops.ptr(self.hyper), int(self.decoupled), self.params.numel(), ops.ptr(self.guard), ops._stream(self.params))
+
+    def _check_overflow(self):
+        """Every GUARD_EVERY steps: look at the skipped-step counter copied back GUARD_EVERY steps ago (no stall), then
+        start the next asynchronous copy.  A moved counter halves the loss scale (graphs are re-captured with it)."""
+        if self._calls % self.GUARD_EVERY:
+            return
+        if not self.params.is_cuda:
+            count = int(self.guard[0])
+        else:
+            count = self._guard_seen
+            if self._guard_ev is not None:
+                self._guard_ev.synchronize()
+                count = int(self._guard_host[0])
+            if self._guard_host is None:
+                self._guard_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._guard_host.copy_(self.guard[:1], non_blocking=True)
+            self._guard_ev = torch.cuda.Event()
+            self._guard_ev.record()
+        if count > self._guard_seen:
+            self._guard_seen = count
+            self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+            self._graphs = None
+            print(' fp16 overflow in the backward pass: %d step(s) skipped so far, loss scale -> %g' % (count, self.loss_scale), flush=True)
 
     def _capture(self):
         """Record the step's ~280 launches into hipGraphs (replayed per step: the host then costs three tiny H2D copies
@@ -357,6 +387,7 @@ class Engine:
         lr = self.lr if lr is None else lr
         hy = ops.adam_hyper(self._state['step'][0], lr, self.beta1, 0.999, 1e-8, self.wd, 1.0)
         self._upload(hy, table, augs, table2, augs2)
+        self._check_overflow()
         use_graph = self.use_graph and shift is None and self.params.is_cuda
         if use_graph and self._graphs is None and self._calls > 2:      # two eager steps first (one-time kernel attributes, allocator warm-up)
             self._capture()

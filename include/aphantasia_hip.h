@@ -166,6 +166,11 @@ int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const
  * d_m may be NULL when beta1 == 0, d_vmax NULL unless amsgrad; decoupled_wd = AdamW */
 int aph_adam_step(float* d_p, const float* d_g, float* d_m, float* d_v, float* d_vmax, const float* d_hyper,
                   int decoupled_wd, size_t n, void* stream);
+/* the same update behind an overflow guard: a gradient with a NaN / inf element (fp16 overflow in the loss-scaled backward)
+ * skips the step and increments d_guard[0] (running count); d_guard[1] is scratch.  d_guard: 2 ints zeroed once by the
+ * caller, who lowers its loss scale when the count moves. */
+int aph_adam_step_guarded(float* d_params, const float* d_grad, float* d_m, float* d_v, float* d_vmax, const float* d_hyper8,
+                          int decoupled_wd, size_t n, int* d_guard2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -300,3 +300,31 @@ def check_frame_affine(lib, dev):
     got = transforms.frame_transform(x.to(dev), (24, 26), 0.0, (0, 0), 1.0, 0.0, lib=lib).cpu()      # identity warp, then pad rows / crop cols
     assert got.shape == (1, 3, 24, 26)
     assert torch.allclose(got[..., 2:22, :], x[..., :, 2:28], atol=1e-5) and float(got[..., :2, :].abs().max()) == 0.0
+
+
+def check_adam_guard(lib, dev):
+    """aph_adam_step_guarded: a NaN / inf anywhere in the gradient skips the step (parameters and moments untouched) and
+    counts it; a finite gradient gives exactly aph_adam_step's update"""
+    from aphantasia_amd import _ffi
+    L = lib if lib is not None else _ffi.lib()
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    p0 = torch.randn(n, generator=g); grad = torch.randn(n, generator=g); v0 = torch.rand(n, generator=g)
+    hyper = torch.tensor(ops.adam_hyper(3, 0.05, 0.0, 0.999, 1e-8, 0.0, 1.0), dtype=torch.float32).to(dev)
+    guard = torch.zeros(2, dtype=torch.int32, device=dev)
+    def run(gr, guarded):
+        p, v = p0.clone().to(dev), v0.clone().to(dev)
+        gr = gr.to(dev)
+        if guarded:
+            L.call('aph_adam_step_guarded', ops.ptr(p), ops.ptr(gr), None, ops.ptr(v), None, ops.ptr(hyper), 0, n, ops.ptr(guard), ops._stream(p))
+        else:
+            L.call('aph_adam_step', ops.ptr(p), ops.ptr(gr), None, ops.ptr(v), None, ops.ptr(hyper), 0, n, ops._stream(p))
+        return p.cpu(), v.cpu()
+    pa, va = run(grad, False)
+    pb, vb = run(grad, True)
+    assert torch.equal(pa, pb) and torch.equal(va, vb) and guard.cpu().tolist()[0] == 0
+    for bad in (float('nan'), float('inf'), -float('inf')):
+        gb = grad.clone(); gb[1234] = bad
+        pc, vc = run(gb, True)
+        assert torch.equal(pc, p0) and torch.equal(vc, v0)
+    assert guard.cpu().tolist()[0] == 3

@@ -101,3 +101,7 @@ def test_rgb_sharp(emu):
 
 def test_frame_affine(emu):
     K.check_frame_affine(emu, 'cpu')
+
+
+def test_adam_guard(emu):
+    K.check_adam_guard(emu, 'cpu')

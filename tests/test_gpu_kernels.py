@@ -123,3 +123,7 @@ def test_rgb_sharp():
 
 def test_frame_affine():
     K.check_frame_affine(None, DEV)
+
+
+def test_adam_guard():
+    K.check_adam_guard(None, DEV)

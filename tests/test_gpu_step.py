@@ -399,3 +399,24 @@ def test_illustrip_frame_loop_reparameterisation(model, gen):
         assert a == b, (frame, a, b)
         assert torch.equal(eng.params, fresh.params)
         eng.reset_params(new)                    # continue the loop from the warped frame
+
+
+def test_loss_scale_backs_off_after_fp16_overflow(model):
+    """an absurd loss scale overflows the fp16 backward: the guarded Adam skips those steps (parameters stay finite), the host
+    halves the scale until the gradient is finite again, and the optimisation then proceeds"""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    seed_all(0)
+    h, w = 256, 320
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+    eng = Engine(params, h, w, model, 6, [(target, -1.0)], sim='mix', transform=transforms.normalize(), loss_scale=2.0 ** 30)
+    eng.GUARD_EVERY = 2
+    p0 = eng.params.clone()
+    first = float(eng.step())
+    assert torch.equal(eng.params, p0)                       # the very first step overflowed and was skipped
+    for _ in range(80):
+        last = float(eng.step())
+    assert eng.loss_scale < 2.0 ** 30 and int(eng.guard[0]) > 0
+    assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, p0)
+    assert last < first - 0.02, (first, last, eng.loss_scale)
