@@ -15,6 +15,7 @@
 // Adjoint of the bilinear warps: gathers through the inverse maps (deterministic as well).
 #include "aph_device.h"
 #include "aph_host.h"
+#include <mutex>
 
 namespace aph {
 
@@ -185,9 +186,40 @@ __device__ __forceinline__ float tap_weight(float scale, int i, int cs, int q) {
   return w;
 }
 
+// Per-cut 1-D tap tables, once per step: for every crop-local source position q of cut s and each axis, the (<= 4)
+// output indices whose clamped cubic taps land on q, with the forward's own fp32 weights and the gradient-layout
+// offsets.  tab[(s * 2 + axis) * maxcs + q]; entries of up-sampling cuts stay unused (generic path).
+template <int OUT>
+__global__ void tap_table_kernel(const int* __restrict__ table, AdjEntry* __restrict__ tab, int maxcs, Geom g) {
+  const int s = blockIdx.z, isrow = blockIdx.y == 0;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cs = table[3 * s];
+  if (q >= cs || q >= maxcs) return;
+  AdjEntry e;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { e.off[a] = 0; e.w[a] = 0.f; }
+  const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
+  if (scale >= 1.0f) {
+    const float inv = 1.0f / scale;
+    int lo = (int)floorf((float)(q - 2) * inv) - 1, hi = (int)floorf((float)(q + 2) * inv) + 1;
+    lo = lo < 0 ? 0 : lo; hi = hi > g.size - 1 ? g.size - 1 : hi;
+    int n = 0;
+    for (int i = lo; i <= hi && n < 4; ++i) {
+      const float w = tap_weight(scale, i, cs, q);
+      if (w != 0.f || n > 0) {             // contiguous run starting at the first non-zero
+        e.w[n] = w;
+        e.off[n] = isrow ? grad_rowpart<OUT>(i, g.size, g.patch) : grad_colpart<OUT>(i, g.size, g.patch);
+        ++n;
+      }
+    }
+  }
+  tab[((size_t)s * 2 + (isrow ? 0 : 1)) * maxcs + q] = e;
+}
+
 template <int OUT>
 __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __restrict__ gout, float gscale,
-                                                                  const int* __restrict__ table, float* __restrict__ grgb, Geom g) {
+                                                                  const int* __restrict__ table, float* __restrict__ grgb, Geom g,
+                                                                  const AdjEntry* __restrict__ tab, int maxcs) {
   constexpr int MAXV = 1024, NB = 8;
   __shared__ int vlist[MAXV];
   __shared__ int vcount;
@@ -248,20 +280,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
             const int q = isrow ? wrap(ty0 + idx + g.py0, g.H) + ay * g.H - oy : wrap(tx0 + (idx - 16) + g.px0, g.W) + ax * g.W - ox;
             const int lim = isrow ? g.Hp : g.Wp;
             const int absq = q + (isrow ? oy : ox);
-            if (q >= 0 && q < cs && absq < lim) {
-              const float inv = 1.0f / scale;
-              int lo = (int)floorf((float)(q - 2) * inv) - 1, hi = (int)floorf((float)(q + 2) * inv) + 1;
-              lo = lo < 0 ? 0 : lo; hi = hi > g.size - 1 ? g.size - 1 : hi;
-              int n = 0;
-              for (int i = lo; i <= hi && n < 4; ++i) {
-                const float w = tap_weight(scale, i, cs, q);
-                if (w != 0.f || n > 0) {             // contiguous run starting at the first non-zero
-                  e.w[n] = w;
-                  e.off[n] = isrow ? grad_rowpart<OUT>(i, g.size, g.patch) : grad_colpart<OUT>(i, g.size, g.patch);
-                  ++n;
-                }
-              }
-            }
+            if (q >= 0 && q < cs && q < maxcs && absq < lim) e = tab[((size_t)s * 2 + (isrow ? 0 : 1)) * maxcs + q];
           }
         } else if (idx == 0) { vinfo[vb][0] = -1; vinfo[vb][1] = 0; }
         ent[vb][idx] = e;
@@ -599,6 +618,34 @@ static int check_geom(const aph_sample_geom* g, int out_mode, const char* who, i
   return APH_OK;
 }
 
+// tap-table workspace of the adjoint: grow-only, owned by the library (one sampler adjoint in flight per process)
+namespace {
+std::mutex g_tab_mu;
+AdjEntry* g_tab = nullptr;
+size_t g_tab_entries = 0;
+
+AdjEntry* ensure_tab(size_t entries) {
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  if (entries > g_tab_entries) {
+    if (g_tab) { (void)hipDeviceSynchronize(); (void)hipFree(g_tab); g_tab = nullptr; g_tab_entries = 0; }
+    if (hipMalloc((void**)&g_tab, entries * sizeof(AdjEntry)) != hipSuccess) return nullptr;
+    g_tab_entries = entries;
+  }
+  return g_tab;
+}
+
+template <int OUT>
+int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, hipStream_t st) {
+  const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;                  // a cut fits the (padded) image; csize <= min(H, W) upstream (utils.py:231,245)
+  AdjEntry* tab = ensure_tab((size_t)g.S * 2 * maxcs);
+  if (!tab) return aph_fail(APH_ERR_HIP, "aph_sample_bwd: cannot allocate the tap tables");
+  APH_LAUNCH(tap_table_kernel<OUT>, dim3((maxcs + 127) / 128, 2, g.S), dim3(128), 0, st, table, tab, maxcs, g);
+  const dim3 agrid((g.W + 15) / 16, (g.H + 15) / 16);
+  APH_LAUNCH(crop_resize_adjoint_kernel<OUT>, agrid, dim3(256), 0, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs);
+  return APH_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* table, const float* aug, float* tmp,
@@ -637,10 +684,12 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
   const int n = g.size;
   const dim3 agrid((g.W + 15) / 16, (g.H + 15) / 16), block(256);
   if (!aug) {
-    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_RAW>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
-    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_NORM>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
-    else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_PATCH_F16>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
-    else APH_LAUNCH(crop_resize_adjoint_kernel<APH_GRAD_PATCH_F16>, agrid, block, 0, st, gout, gscale, (const int*)table, grgb, g);
+    int rc;
+    if (out_mode == APH_OUT_NCHW_RAW) rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>(gout, gscale, (const int*)table, grgb, g, st);
+    else if (out_mode == APH_OUT_NCHW_NORM) rc = launch_crop_adjoint<APH_OUT_NCHW_NORM>(gout, gscale, (const int*)table, grgb, g, st);
+    else if (out_mode == APH_OUT_PATCH_F16) rc = launch_crop_adjoint<APH_OUT_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, st);
+    else rc = launch_crop_adjoint<APH_GRAD_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, st);
+    if (rc) return rc;
     return aph_check_launch("aph_sample_bwd");
   }
   const size_t per = (size_t)g.S * 3 * n * n;
@@ -652,7 +701,7 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
   else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else APH_LAUNCH(rotate_emit_adjoint_kernel<APH_GRAD_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   APH_LAUNCH(persp_adjoint_kernel, grid, block, 0, st, (const float*)dB, aug, dA, n);
-  APH_LAUNCH(crop_resize_adjoint_kernel<APH_OUT_NCHW_RAW>, agrid, block, 0, st, (const void*)dA, gscale, (const int*)table, grgb, g);
+  if (int rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>((const void*)dA, gscale, (const int*)table, grgb, g, st)) return rc;
   return aph_check_launch("aph_sample_bwd");
   APH_CATCH
 }
