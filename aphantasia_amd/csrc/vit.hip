@@ -177,8 +177,14 @@ void launch_attn_fwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
 void launch_attn_bwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
   const int T = v->T;
   if (T <= AT_T)       // (the split dQ / dKdV kernels with NB = 1 were measured slower here: 7.62 vs 7.35 ms per C2 step)
-    APH_LAUNCH(attn_bwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
-               (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+  {
+    if (T <= AT_RB)
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
+                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+    else
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_T>, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
+                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+  }
   else if (T <= 128) launch_attn_bwd_g<2>(v, l, S, st);
   else if (T <= 192) launch_attn_bwd_g<3>(v, l, S, st);
   else launch_attn_bwd_g<4>(v, l, S, st);

@@ -17,6 +17,7 @@
 namespace aph {
 
 constexpr int AT_T = 64;                       // padded sequence length
+constexpr int AT_RB = 56;                      // row-major LDS tiles of the one-tile backward keep 56 rows when T <= 56 (ViT-B/32: T = 50)
 __device__ __forceinline__ int slot_of(int n) { return ((n >> 5) << 5) + (((n >> 2) & 3) << 3) + (((n >> 4) & 1) << 2) + (n & 3); }
 
 // [64 rows][64 halfs] tile, 16-byte chunks XOR-swizzled exactly like the GEMM tiles (conflict-free b128 reads)
@@ -28,7 +29,7 @@ __device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((
 // transposes the 8x8 block in registers and writes 8 + 8 full 16-byte chunks -- no scattered 2-byte LDS stores, no
 // separate zero fill, and the 8 lanes of a store group hit 8 different 16-byte slots of one 128-byte row.
 __device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, int ld, int T, int item, half_t* rowmajor,
-                                              half_t* transposed) {
+                                              half_t* transposed, int row_limit = 64) {
   const int c = item >> 3, sc = item & 7;
   const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);          // rows n(sc, i) = nbase + (i >> 2) * 16 + (i & 3)
   half8 rows[8];
@@ -40,7 +41,10 @@ __device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, in
   }
   if (rowmajor) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<half8*>(rowmajor + at_off(nbase + ((i >> 2) << 4) + (i & 3), c)) = rows[i];
+    for (int i = 0; i < 8; ++i) {
+      const int n = nbase + ((i >> 2) << 4) + (i & 3);
+      if (n < row_limit) *reinterpret_cast<half8*>(rowmajor + at_off(n, c)) = rows[i];
+    }
   }
   if (transposed) {
 #pragma unroll
@@ -55,6 +59,11 @@ __device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, in
 
 __device__ __forceinline__ half8 at_frag(const half_t* tile, int row, int chunk) {
   return *reinterpret_cast<const half8*>(tile + at_off(row, chunk));
+}
+// fragment of a row-major tile that only holds rows < limit (the rest are zero by construction)
+__device__ __forceinline__ half8 at_frag_rows(const half_t* tile, int row, int chunk, int limit) {
+  const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return row < limit ? *reinterpret_cast<const half8*>(tile + at_off(row, chunk)) : z;
 }
 
 __device__ __forceinline__ half8 pack8(const f32x4& a, const f32x4& b) {
@@ -127,18 +136,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
 }
 
 // backward: (qkv, att, lse, datt) -> dqkv [M,3D] f16
+template <int RB>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
                                                            const half_t* __restrict__ datt, const float* __restrict__ lse,
                                                            half_t* __restrict__ dqkv, int T, int heads) {
-  __shared__ __attribute__((aligned(16))) half_t lds[7 * 64 * 64 + 256];
+  constexpr int RT = RB * 64;                    // halfs per row-major tile
+  __shared__ __attribute__((aligned(16))) half_t lds[4 * RT + 3 * 4096 + 256];
   half_t* Qs = lds;
-  half_t* Ks = lds + 1 * 4096;
-  half_t* Vs = lds + 2 * 4096;
-  half_t* Os = lds + 3 * 4096;   // dO
-  half_t* Qt = lds + 4 * 4096;
-  half_t* Kt = lds + 5 * 4096;
-  half_t* Ot = lds + 6 * 4096;   // dO transposed
-  float* Ls = reinterpret_cast<float*>(lds + 7 * 4096);
+  half_t* Ks = lds + 1 * RT;
+  half_t* Vs = lds + 2 * RT;
+  half_t* Os = lds + 3 * RT;      // dO
+  half_t* Qt = lds + 4 * RT;
+  half_t* Kt = Qt + 4096;
+  half_t* Ot = Kt + 4096;         // dO transposed
+  float* Ls = reinterpret_cast<float*>(Ot + 4096);
   float* Ds = Ls + 64;
   const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
   const int D = heads * 64, ld = 3 * D;
@@ -147,10 +158,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
   const half_t* ob = att + (size_t)s * T * D + h * 64;
   {
     const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
-    if (which == 0) at_stage_item(base, ld, T, item, Qs, Qt);
-    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, Kt);
-    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, Vs, nullptr);
-    else at_stage_item(dob, D, T, item, Os, Ot);
+    if (which == 0) at_stage_item(base, ld, T, item, Qs, Qt, RB);
+    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, Kt, RB);
+    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, Vs, nullptr, RB);
+    else at_stage_item(dob, D, T, item, Os, Ot, RB);
   }
   {
     // D_i = dO_i . O_i : 4 threads per row
@@ -183,11 +194,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
     for (int jt = 0; jt < 4; ++jt) { st[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
-      const half8 qf = at_frag(Qs, i, kd * 4 + g), of = at_frag(Os, i, kd * 4 + g);
+      const half8 qf = at_frag_rows(Qs, i, kd * 4 + g, RB), of = at_frag_rows(Os, i, kd * 4 + g, RB);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        st[jt] = mfma_16x16x32_f16(at_frag(Ks, jt * 16 + c16, kd * 4 + g), qf, st[jt]);
-        dp[jt] = mfma_16x16x32_f16(at_frag(Vs, jt * 16 + c16, kd * 4 + g), of, dp[jt]);
+        st[jt] = mfma_16x16x32_f16(at_frag_rows(Ks, jt * 16 + c16, kd * 4 + g, RB), qf, st[jt]);
+        dp[jt] = mfma_16x16x32_f16(at_frag_rows(Vs, jt * 16 + c16, kd * 4 + g, RB), of, dp[jt]);
       }
     }
     const float Li = Ls[i], Di = Ds[i];
@@ -213,11 +224,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
     for (int t = 0; t < 4; ++t) { sq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
-      const half8 kf = at_frag(Ks, j, kd * 4 + g), vf = at_frag(Vs, j, kd * 4 + g);
+      const half8 kf = at_frag_rows(Ks, j, kd * 4 + g, RB), vf = at_frag_rows(Vs, j, kd * 4 + g, RB);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        sq[t] = mfma_16x16x32_f16(at_frag(Qs, t * 16 + c16, kd * 4 + g), kf, sq[t]);
-        dq[t] = mfma_16x16x32_f16(at_frag(Os, t * 16 + c16, kd * 4 + g), vf, dq[t]);
+        sq[t] = mfma_16x16x32_f16(at_frag_rows(Qs, t * 16 + c16, kd * 4 + g, RB), kf, sq[t]);
+        dq[t] = mfma_16x16x32_f16(at_frag_rows(Os, t * 16 + c16, kd * 4 + g, RB), vf, dq[t]);
       }
     }
     f32x4 pp[4];
