@@ -166,7 +166,7 @@ __device__ __forceinline__ int grad_rowpart(int i, int size, int p) {
   return i * size;
 }
 template <int OUT>
-__device__ __forceinline__ int grad_colpart(int j, int size, int p) {
+__device__ __forceinline__ int grad_colpart(int j, int /*size*/, int p) {
   if (is_patch<OUT>::v) return (j / p) * (3 * p * p) + (j % p);
   return j;
 }

@@ -99,13 +99,12 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
   const int wm = wave / C::WN, wn = wave - wm * C::WN;
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, speed only).  Every XCD gets one contiguous
   // run of tiles, n-tiles fastest.  Bijective for any grid size.
-  int m0, n0, tile_id = 0, split = 0;
+  int m0, n0, split = 0;
   {
     int nwg = gridDim.x, b = blockIdx.x;
     if (SK) { split = b % sk.splits; b /= sk.splits; nwg /= sk.splits; }
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_id = tile;
     const int ntn = N / C::BN;
     const int tm = tile / ntn;
     n0 = (tile - tm * ntn) * C::BN;
