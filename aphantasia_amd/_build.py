@@ -14,7 +14,7 @@ def _stale():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'aphantasia_hip.h')]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'aphantasia_hip.h'), os.path.join(ROOT, 'include', 'aphantasia_hip_test.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -33,6 +33,8 @@ _PROTOTYPES = {
     'aph_synth_plan_destroy': (c_int, [c_void_p]),
     'aph_synth_fft_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, POINTER(c_float), c_int, c_void_p, c_void_p, c_void_p]),
     'aph_synth_fft_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
+    'aph_irfft2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'aph_rfft2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_synth_spatial_fwd': (c_int, [c_void_p, c_void_p, c_float, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_synth_spatial_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_synth_stats': (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -42,6 +44,7 @@ _PROTOTYPES = {
     'aph_rgb_priors': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_idwt_level_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'aph_idwt_level_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'aph_sample_ws_bytes': (c_size_t, [POINTER(SampleGeom), c_int]),
     'aph_sample_fwd': (c_int, [POINTER(SampleGeom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_sample_bwd': (c_int, [POINTER(SampleGeom), c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'aph_frame_affine': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),

@@ -114,13 +114,18 @@ def text_embedding(model, text, device='cuda'):
     """Target embedding for a prompt ([1, output_dim], detached).  Real text tower when available,
     else a deterministic synthetic vector derived from the prompt (so runs are reproducible)."""
     if not model.synthetic:
+        # a real checkpoint: the target must come from its text tower -- a random stand-in would silently optimise towards
+        # nothing while the output still looks like a valid run
         try:
-            import clip as openai_clip          # the reference's dependency; optional here
-            full = openai_clip.model.build_model(model._full_state).float().to(device).eval()
-            with torch.no_grad():
-                return full.encode_text(openai_clip.tokenize(text).to(device)).detach().clone().float()
-        except ImportError:
-            warnings.warn('`clip` package not importable: falling back to a synthetic text embedding for %r' % text)
+            import clip as openai_clip          # the reference's dependency (openai/CLIP); tokenizer + text tower
+        except ImportError as e:
+            raise RuntimeError('text prompts with a real CLIP checkpoint need the `clip` package (openai/CLIP: BPE vocabulary + text '
+                               'tower); it is not importable here.  Pass image prompts (-i) or install it.') from e
+        if getattr(model, '_text_model', None) is None:
+            import copy
+            model._text_model = openai_clip.model.build_model(copy.copy(model._full_state)).float().to(device).eval()
+        with torch.no_grad():
+            return model._text_model.encode_text(openai_clip.tokenize(text).to(device)).detach().clone().float()
     h = int.from_bytes(hashlib.sha256(text.encode()).digest()[:4], 'little')
     g = torch.Generator().manual_seed(h)
     return torch.randn(1, model.visual.output_dim, generator=g).to(device)

@@ -11,8 +11,10 @@
 #define APH_LAUNCH(kern, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define APH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-// kernels that ask for more than 64 KiB of dynamic LDS must opt in once
-#define APH_ALLOW_SMEM(kern, bytes) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+// kernels that ask for more than 64 KiB of dynamic LDS must opt in once per device: checked, remembered per (kernel, device)
+// (api.hip); throws std::runtime_error on failure, which the C ABI's APH_CATCH turns into an error code
+void aph_allow_smem(const void* kernel, int bytes);
+#define APH_ALLOW_SMEM(kern, bytes) aph_allow_smem(reinterpret_cast<const void*>(kern), (int)(bytes))
 #endif
 
 #include <stdint.h>

@@ -18,7 +18,24 @@ int aph_check_launch(const char* where) {
   return APH_OK;
 }
 
+#ifndef APH_EMU
+#include <mutex>
+#include <unordered_map>
+void aph_allow_smem(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<unsigned long long, int> granted;     // (kernel, device) -> largest size granted
+  int dev = 0;
+  APH_HIP(hipGetDevice(&dev));
+  const unsigned long long key = (unsigned long long)(uintptr_t)kernel * 64ull + (unsigned long long)(dev & 63);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = granted.find(key);
+  if (it != granted.end() && it->second >= bytes) return;
+  APH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  granted[key] = bytes;
+}
+#endif
+
 extern "C" {
-int aph_version(void) { return 100; }
+int aph_version(void) { return 200; }
 const char* aph_last_error(void) { return g_err; }
 }

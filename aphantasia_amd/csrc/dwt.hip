@@ -162,15 +162,13 @@ __global__ __launch_bounds__(256) void idwt_level_adjoint_kernel(const float* __
 template <int H2T>
 void launch_idwt_fwd(dim3 grid, size_t smem, hipStream_t st, const float* d_ll, int ll_h, int ll_w, const float* d_highs, int h, int w,
                      const float* d_g0, const float* d_g1, int L, float hscale, float* d_out, int Ho, int Wo) {
-  static bool once = (APH_ALLOW_SMEM(idwt_level_kernel<H2T>, 150 * 1024), true);
-  (void)once;
+  APH_ALLOW_SMEM(idwt_level_kernel<H2T>, 150 * 1024);
   APH_LAUNCH(idwt_level_kernel<H2T>, grid, dim3(256), smem, st, d_ll, ll_h, ll_w, d_highs, h, w, d_g0, d_g1, L, hscale, d_out, Ho, Wo);
 }
 template <int LT>
 void launch_idwt_bwd(dim3 grid, size_t smem, hipStream_t st, const float* d_out_grad, int Ho, int Wo, int h, int w, const float* d_g0,
                      const float* d_g1, int L, float hscale, float* d_ll_grad, int ll_h, int ll_w, float* d_highs_grad) {
-  static bool once = (APH_ALLOW_SMEM(idwt_level_adjoint_kernel<LT>, 150 * 1024), true);
-  (void)once;
+  APH_ALLOW_SMEM(idwt_level_adjoint_kernel<LT>, 150 * 1024);
   APH_LAUNCH(idwt_level_adjoint_kernel<LT>, grid, dim3(256), smem, st, d_out_grad, Ho, Wo, h, w, d_g0, d_g1, L, hscale, d_ll_grad, ll_h,
              ll_w, d_highs_grad);
 }

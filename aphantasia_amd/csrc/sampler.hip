@@ -15,7 +15,6 @@
 // Adjoint of the bilinear warps: gathers through the inverse maps (deterministic as well).
 #include "aph_device.h"
 #include "aph_host.h"
-#include <mutex>
 
 namespace aph {
 
@@ -618,27 +617,19 @@ static int check_geom(const aph_sample_geom* g, int out_mode, const char* who, i
   return APH_OK;
 }
 
-// tap-table workspace of the adjoint: grow-only, owned by the library (one sampler adjoint in flight per process)
+// Workspace of one sampler call (caller-owned, aph_sample_ws_bytes): [per-cut 1-D tap tables of the crop adjoint |
+// cut scratch A | cut scratch B], the scratch planes only with geometric augmentation.  Nothing is allocated or freed
+// in a launch path, so a captured hipGraph never holds a pointer the library could invalidate.
 namespace {
-std::mutex g_tab_mu;
-AdjEntry* g_tab = nullptr;
-size_t g_tab_entries = 0;
-
-AdjEntry* ensure_tab(size_t entries) {
-  std::lock_guard<std::mutex> lk(g_tab_mu);
-  if (entries > g_tab_entries) {
-    if (g_tab) { (void)hipDeviceSynchronize(); (void)hipFree(g_tab); g_tab = nullptr; g_tab_entries = 0; }
-    if (hipMalloc((void**)&g_tab, entries * sizeof(AdjEntry)) != hipSuccess) return nullptr;
-    g_tab_entries = entries;
-  }
-  return g_tab;
+size_t tab_bytes(const Geom& g) {
+  const size_t maxcs = (size_t)(g.Hp < g.Wp ? g.Hp : g.Wp);    // a cut fits the (padded) image; csize <= min(H, W) upstream (utils.py:231,245)
+  return ((size_t)g.S * 2 * maxcs * sizeof(AdjEntry) + 255) & ~(size_t)255;
 }
+size_t scratch_floats(const Geom& g) { return (size_t)g.S * 3 * g.size * g.size; }
 
 template <int OUT>
-int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, hipStream_t st) {
-  const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;                  // a cut fits the (padded) image; csize <= min(H, W) upstream (utils.py:231,245)
-  AdjEntry* tab = ensure_tab((size_t)g.S * 2 * maxcs);
-  if (!tab) return aph_fail(APH_ERR_HIP, "aph_sample_bwd: cannot allocate the tap tables");
+int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, AdjEntry* tab, hipStream_t st) {
+  const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;
   APH_LAUNCH(tap_table_kernel<OUT>, dim3((maxcs + 127) / 128, 2, g.S), dim3(128), 0, st, table, tab, maxcs, g);
   const dim3 agrid((g.W + 15) / 16, (g.H + 15) / 16);
   APH_LAUNCH(crop_resize_adjoint_kernel<OUT>, agrid, dim3(256), 0, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs);
@@ -648,11 +639,17 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
 
 extern "C" {
 
-int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* table, const float* aug, float* tmp,
+size_t aph_sample_ws_bytes(const aph_sample_geom* gg, int with_aug) {
+  if (!gg || gg->S < 1 || gg->size < 1 || gg->Hp < 1 || gg->Wp < 1) return 0;
+  const Geom g = to_geom(gg);
+  return tab_bytes(g) + (with_aug ? 2 * scratch_floats(g) * sizeof(float) : 0);
+}
+
+int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* table, const float* aug, void* ws,
                    void* out, int out_mode, void* stream_) {
   APH_TRY
   if (int e = check_geom(gg, out_mode, "aph_sample_fwd")) return e;
-  if (!rgb || !table || !out || (aug && !tmp)) return aph_fail(APH_ERR_ARG, "aph_sample_fwd: null argument");
+  if (!rgb || !table || !out || (aug && !ws)) return aph_fail(APH_ERR_ARG, "aph_sample_fwd: null argument");
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
   const int n = g.size;
@@ -663,8 +660,8 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
     else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g);
     return aph_check_launch("aph_sample_fwd");
   }
-  float* A = tmp;
-  float* Bv = tmp + (size_t)g.S * 3 * n * n;
+  float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
+  float* Bv = A + scratch_floats(g);
   APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g);
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
@@ -675,33 +672,33 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
 }
 
 int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, const int32_t* table, const float* aug,
-                   float* tmp, float* grgb, int out_mode, void* stream_) {
+                   void* ws, float* grgb, int out_mode, void* stream_) {
   APH_TRY
   if (int e = check_geom(gg, out_mode, "aph_sample_bwd", APH_GRAD_PATCH_F16)) return e;
-  if (!gout || !table || !grgb || (aug && !tmp)) return aph_fail(APH_ERR_ARG, "aph_sample_bwd: null argument");
+  if (!gout || !table || !grgb || !ws) return aph_fail(APH_ERR_ARG, "aph_sample_bwd: null argument (the workspace of aph_sample_ws_bytes is required)");
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
   const int n = g.size;
-  const dim3 agrid((g.W + 15) / 16, (g.H + 15) / 16), block(256);
+  const dim3 block(256);
+  AdjEntry* tab = static_cast<AdjEntry*>(ws);
   if (!aug) {
     int rc;
-    if (out_mode == APH_OUT_NCHW_RAW) rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>(gout, gscale, (const int*)table, grgb, g, st);
-    else if (out_mode == APH_OUT_NCHW_NORM) rc = launch_crop_adjoint<APH_OUT_NCHW_NORM>(gout, gscale, (const int*)table, grgb, g, st);
-    else if (out_mode == APH_OUT_PATCH_F16) rc = launch_crop_adjoint<APH_OUT_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, st);
-    else rc = launch_crop_adjoint<APH_GRAD_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, st);
+    if (out_mode == APH_OUT_NCHW_RAW) rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>(gout, gscale, (const int*)table, grgb, g, tab, st);
+    else if (out_mode == APH_OUT_NCHW_NORM) rc = launch_crop_adjoint<APH_OUT_NCHW_NORM>(gout, gscale, (const int*)table, grgb, g, tab, st);
+    else if (out_mode == APH_OUT_PATCH_F16) rc = launch_crop_adjoint<APH_OUT_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, tab, st);
+    else rc = launch_crop_adjoint<APH_GRAD_PATCH_F16>(gout, gscale, (const int*)table, grgb, g, tab, st);
     if (rc) return rc;
     return aph_check_launch("aph_sample_bwd");
   }
-  const size_t per = (size_t)g.S * 3 * n * n;
-  float* dA = tmp;
-  float* dB = tmp + per;
+  float* dA = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
+  float* dB = dA + scratch_floats(g);
   const dim3 grid((n * n + 255) / 256, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else APH_LAUNCH(rotate_emit_adjoint_kernel<APH_GRAD_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   APH_LAUNCH(persp_adjoint_kernel, grid, block, 0, st, (const float*)dB, aug, dA, n);
-  if (int rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>((const void*)dA, gscale, (const int*)table, grgb, g, st)) return rc;
+  if (int rc = launch_crop_adjoint<APH_OUT_NCHW_RAW>((const void*)dA, gscale, (const int*)table, grgb, g, tab, st)) return rc;
   return aph_check_launch("aph_sample_bwd");
   APH_CATCH
 }

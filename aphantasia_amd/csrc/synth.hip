@@ -145,7 +145,7 @@ __global__ void fft_col_synth_kernel(const float2* __restrict__ params, const fl
     float2 v = make_float2(0.f, 0.f);
     if (g < G) {
       const int c = g / Wc, kx = g - c * Wc;
-      const float s = scale[ky * Wc + kx];
+      const float s = scale ? scale[ky * Wc + kx] : 1.0f;
       v = params[((size_t)c * H + ky) * Wc + kx];
       v.x *= s; v.y *= s;
       if (shift) { const float sh = s * shift[ky * Wc + kx]; v.x += sh; v.y += sh; }
@@ -186,7 +186,7 @@ __global__ void fft_col_adjoint_kernel(const float2* __restrict__ tmp, const flo
     const int t = idx % TC, ky = idx / TC, g = g0 + t;
     if (g < G) {
       const int c = g / Wc, kx = g - c * Wc;
-      const float s = scale[ky * Wc + kx];
+      const float s = scale ? scale[ky * Wc + kx] : 1.0f;
       float2 v = r[t * H + ky];
       grad[((size_t)c * H + ky) * Wc + kx] = make_float2(v.x * s, v.y * s);
     }
@@ -242,7 +242,7 @@ __global__ void fft_row_synth_kernel(const float2* __restrict__ tmp, float* __re
 // fused into the load:  d raw = A * dn + B * (raw - mean)   (bstats = {A, B, mean}).
 __global__ void fft_row_adjoint_kernel(const float* __restrict__ dn, const float* __restrict__ raw,
                                        const float* __restrict__ bstats, float2* __restrict__ tmp, Fft1D plan,
-                                       const float2* __restrict__ tw, int H, int W, int Wc, float norm) {
+                                       const float2* __restrict__ tw, int H, int W, int Wc, float norm, int plain) {
   APH_DYN_SMEM(smem);
   float2* a = reinterpret_cast<float2*>(smem);
   float2* b = a + W;
@@ -250,7 +250,8 @@ __global__ void fft_row_adjoint_kernel(const float* __restrict__ dn, const float
   const int c = blockIdx.x / pairs, p = blockIdx.x - c * pairs;
   const int y0 = 2 * p, y1 = 2 * p + 1;
   const bool has1 = y1 < H;
-  const float A = bstats[0], Bc = bstats[1], mu = bstats[2];
+  // plain: the forward transform rfft2 itself (aph_rfft2) -- no normalisation adjoint, no doubling of interior columns
+  const float A = plain ? 1.0f : bstats[0], Bc = plain ? 0.0f : bstats[1], mu = plain ? 0.0f : bstats[2];
   const size_t o0 = ((size_t)c * H + y0) * W, o1 = ((size_t)c * H + y1) * W;
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
     const float g0 = A * dn[o0 + x] + Bc * (raw[o0 + x] - mu);
@@ -265,7 +266,7 @@ __global__ void fft_row_adjoint_kernel(const float* __restrict__ dn, const float
     const float2 z = r[k];
     const float2 zc = r[k == 0 ? 0 : W - k];
     // Ga = (Z[k] + conj(Z[-k])) / 2 ; Gb = (Z[k] - conj(Z[-k])) / (2i)
-    const float f = ((k >= 1 && k <= W - Wc) ? 1.0f : 0.5f) * norm;
+    const float f = ((!plain && k >= 1 && k <= W - Wc) ? 1.0f : 0.5f) * norm;
     t0[k] = make_float2((z.x + zc.x) * f, (z.y - zc.y) * f);
     if (has1) t1[k] = make_float2((z.y + zc.y) * f, (zc.x - z.x) * f);
   }
@@ -608,11 +609,43 @@ int aph_synth_fft_bwd(aph_synth_plan* p, const float* d_rgb, float gscale, const
              (double)p->C * p->H * p->W, (const float*)p->stats, contrast, 0.f, p->bstats);
   const float norm = (float)(1.0 / sqrt((double)p->H * (double)p->W));
   APH_LAUNCH(fft_row_adjoint_kernel, dim3(p->nrow_blocks), dim3(256), sizeof(float2) * 2 * p->W, st, (const float*)p->dn, raw,
-             (const float*)p->bstats, p->tmp, p->pw, (const float2*)p->twW, p->H, p->W, p->Wc, norm);
+             (const float*)p->bstats, p->tmp, p->pw, (const float2*)p->twW, p->H, p->W, p->Wc, norm, 0);
   const int G = p->C * p->Wc;
   APH_LAUNCH(fft_col_adjoint_kernel, dim3((G + p->TC - 1) / p->TC), dim3(p->col_threads), sizeof(float2) * 2 * p->TC * p->H, st,
              (const float2*)p->tmp, scale, (float2*)grad_params, p->ph, (const float2*)p->twH, p->C, p->H, p->Wc, p->TC);
   return aph_check_launch("aph_synth_fft_bwd");
+  APH_CATCH
+}
+
+// Standalone transforms on the plan's geometry, torch.fft semantics with norm='ortho' (illustrip.py:401-409: the per-frame
+// irfftn -> warp -> rfftn round trip of `--gen FFT`).
+//   aph_irfft2: spectrum [C,H,Wc,2] -> image [C,H,W]   (= torch.fft.irfftn(view_as_complex(x), s=(H,W), norm='ortho'))
+//   aph_rfft2:  image [C,H,W] -> spectrum [C,H,Wc,2]   (= view_as_real(torch.fft.rfftn(x, s=(H,W), dim=[-2,-1], norm='ortho')))
+int aph_irfft2(aph_synth_plan* p, const float* spectrum, float* image, void* stream_) {
+  APH_TRY
+  if (!p || !spectrum || !image) return aph_fail(APH_ERR_ARG, "aph_irfft2: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const int G = p->C * p->Wc;
+  APH_LAUNCH(fft_col_synth_kernel, dim3((G + p->TC - 1) / p->TC), dim3(p->col_threads), sizeof(float2) * 2 * p->TC * p->H, st,
+             (const float2*)spectrum, (const float*)nullptr, (const float*)nullptr, p->tmp, p->ph, (const float2*)p->twH, p->C, p->H, p->Wc, p->TC);
+  const float norm = (float)(1.0 / sqrt((double)p->H * (double)p->W));
+  APH_LAUNCH(fft_row_synth_kernel, dim3(p->nrow_blocks), dim3(256), sizeof(float2) * 2 * p->W, st,
+             (const float2*)p->tmp, image, p->partials, p->pw, (const float2*)p->twW, p->H, p->W, p->Wc, norm);
+  return aph_check_launch("aph_irfft2");
+  APH_CATCH
+}
+
+int aph_rfft2(aph_synth_plan* p, const float* image, float* spectrum, void* stream_) {
+  APH_TRY
+  if (!p || !image || !spectrum) return aph_fail(APH_ERR_ARG, "aph_rfft2: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const float norm = (float)(1.0 / sqrt((double)p->H * (double)p->W));
+  APH_LAUNCH(fft_row_adjoint_kernel, dim3(p->nrow_blocks), dim3(256), sizeof(float2) * 2 * p->W, st, image, image,
+             (const float*)nullptr, p->tmp, p->pw, (const float2*)p->twW, p->H, p->W, p->Wc, norm, 1);
+  const int G = p->C * p->Wc;
+  APH_LAUNCH(fft_col_adjoint_kernel, dim3((G + p->TC - 1) / p->TC), dim3(p->col_threads), sizeof(float2) * 2 * p->TC * p->H, st,
+             (const float2*)p->tmp, (const float*)nullptr, (float2*)spectrum, p->ph, (const float2*)p->twH, p->C, p->H, p->Wc, p->TC);
+  return aph_check_launch("aph_rfft2");
   APH_CATCH
 }
 

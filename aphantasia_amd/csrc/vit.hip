@@ -116,12 +116,12 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
   if (!v->prof_on) { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); return; }
   if (v->prof_used + 2 > v->prof_ev.size()) {
     hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    APH_HIP(hipEventCreate(&a)); APH_HIP(hipEventCreate(&b));
     v->prof_ev.push_back(a); v->prof_ev.push_back(b);
   }
-  (void)hipEventRecord(v->prof_ev[v->prof_used], st);
+  APH_HIP(hipEventRecord(v->prof_ev[v->prof_used], st));
   launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk);
-  (void)hipEventRecord(v->prof_ev[v->prof_used + 1], st);
+  APH_HIP(hipEventRecord(v->prof_ev[v->prof_used + 1], st));
   v->prof_used += 2;
   v->prof_flops += 2.0 * M * N * K;
 }
@@ -153,15 +153,14 @@ void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const
 template <int NB>
 void launch_attn_fwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NB * 8192;
-  static bool once = (APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem), true);
-  (void)once;
+  APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem);
   APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem, st, (const half_t*)l.qkv, l.att, l.lse, v->T, v->heads);
 }
 template <int NB>
 void launch_attn_bwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
   constexpr size_t smem_q = (size_t)3 * NB * 8192, smem_kv = (size_t)4 * NB * 8192 + 2 * NB * 64 * sizeof(float);
-  static bool once = (APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q), APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv), true);
-  (void)once;
+  APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q);
+  APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv);
   APH_LAUNCH((attn_bwd_dq_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_q, st, (const half_t*)l.qkv, (const half_t*)l.att,
              (const half_t*)v->datt, (const float*)l.lse, v->delta, v->dqkv, v->T, v->heads);
   APH_LAUNCH((attn_bwd_dkv_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_kv, st, (const half_t*)l.qkv, (const half_t*)v->datt,
@@ -222,6 +221,7 @@ int aph_vit_create(int input_resolution, int patch_size, int width, int layers, 
 
 int aph_vit_destroy(aph_vit* v) {
   if (!v) return APH_OK;
+  for (hipEvent_t e : v->prof_ev) (void)hipEventDestroy(e);
   (void)hipFree(v->arena);
   delete v;
   return APH_OK;
@@ -314,14 +314,14 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
   // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
-  (void)hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st);
+  APH_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st));
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];
     const bool cls_only = li + 1 == v->L;          // see aph_vit_forward: the last block's MLP / out-proj saw class rows only
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
-    if (cls_only) (void)hipMemsetAsync(v->datt, 0, sizeof(half_t) * (size_t)M * D, st);   // no gradient into the other rows' attention output
+    if (cls_only) APH_HIP(hipMemsetAsync(v->datt, 0, sizeof(half_t) * (size_t)M * D, st));   // no gradient into the other rows' attention output
     vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);

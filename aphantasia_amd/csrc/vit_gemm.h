@@ -482,8 +482,7 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
 
 template <class C, class Epi>
 inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false>), C::SMEM), true);
-  (void)once;
+  APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false>), C::SMEM);
   APH_LAUNCH((gemm_f16_kernel<C, Epi, false>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt,
              ldb, M, N, K, epi, SplitK{nullptr, 1});
 }
@@ -510,8 +509,7 @@ inline int choose_splits(int M, int N, int K, const SplitKSpace* sp) {
 template <class C, class Epi>
 inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, int splits,
                                const SplitKSpace& sp, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true>), C::SMEM), true);
-  (void)once;
+  APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true>), C::SMEM);
   const int tiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
   APH_LAUNCH((gemm_f16_kernel<C, Epi, true>), dim3(tiles * splits), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi,
              SplitK{sp.ws, splits});
@@ -521,8 +519,7 @@ inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int l
 
 template <class Epi>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  static bool once = (APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM), true);
-  (void)once;
+  APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM);
   APH_LAUNCH((gemm8_f16_kernel<Epi>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st,
              A, lda, Bt, ldb, M, N, K, epi);
 }

@@ -60,6 +60,15 @@ class Engine:
         self.lo, self.hi = shard_range(self.S, rank, world)
         self.S_loc = self.hi - self.lo
         self.sim = sim
+        if ops._sim_key(sim) == 'dot':
+            # dot_compare (utils.py:270-274) is dot^2 / (eps + |v2|) over ALL cuts at once: not a mean of per-cut terms, so a
+            # rank's shard cannot form it, and with --enforce / --expand the reference takes the magnitude from the OTHER
+            # operand (out_enc2 / prev_enc) while the fused kernel takes it from the current encodings
+            if world > 1:
+                raise NotImplementedError("sim 'dot' needs sums over all cuts; it is single-GPU only in the fused engine")
+            if float(enforce) != 0 or float(expand) > 0:
+                raise NotImplementedError("sim 'dot' with --enforce / --expand is not supported in the fused engine "
+                                          "(use the drop-in autograd API: aphantasia_amd.utils.sim_func composes it from torch ops)")
         self.rng_mode = rng
         # hipGraph replay is a single-rank optimisation (it only saves host time; on the 128-core GPU box eager launches
         # measure the same step time at every shard size).  Multi-rank runs launch eagerly: graph replays next to a
@@ -67,7 +76,7 @@ class Engine:
         # bench.py performs (reproduced with gloo on one device and with RCCL at world size 1; eager launches never did).
         if world > 1:
             use_graph = False
-        self.use_graph, self._graphs, self._calls = use_graph, None, 0
+        self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
         self.sharp, self.expand = float(sharp), float(expand)       # clip_fft.py:269-270, :276-280
@@ -120,7 +129,7 @@ class Engine:
         self.grad = torch.empty_like(params)
         self.loss = torch.zeros(1, **f32)
         self.prior_ws = torch.empty(int(self.lib.cdll.aph_rgb_priors_ws_bytes()) // 8, device=self.dev, dtype=torch.float64)
-        self.ws = torch.empty(Sl * (len(targets) + 2), **f32)
+        self.ws = torch.empty(Sl * (len(self.coef) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.dev)      # [skipped-step count, scratch]
         self._own_stream = None
@@ -129,7 +138,7 @@ class Engine:
         self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
         self.geometric = isinstance(transform, Transform) and transform.geometric
         self.aug = torch.empty(Sl, _ffi.APH_AUG_STRIDE, **f32) if self.geometric else None
-        self.tmp = torch.empty(2 * Sl * 3 * self.size * self.size, **f32) if self.geometric else None
+        self.tmp = ops.sample_ws(self.geom, self.geometric, self.dev, self.lib)      # engine-owned: tap tables + augmentation scratch
         if self.enforce != 0:          # second, independently drawn set of cuts of the same image
             self.table2 = torch.empty_like(self.table)
             self.aug2 = torch.empty_like(self.aug) if self.geometric else None
@@ -155,11 +164,14 @@ class Engine:
                 raise ValueError('per-cut target has %d rows, expected %d' % (t.shape[0], self.S))
         if self.expand > 0:          # slot of the previous step's encodings (clip_fft.py:276-280); inactive (coef 0) until one exists
             per = per + [(torch.ones(self.S, bro[0][0].shape[-1] if bro else per[0][0].shape[-1]), 0.0)]
+        self._graphs = None          # captured graphs hold the old target / coefficient pointers
         self.n_broadcast = len(bro)
         self.targets = torch.cat([t.reshape(-1, t.shape[-1]).float().to(self.dev) for t, _ in bro + per], 0).contiguous()
         self.coef = [float(c) for _, c in bro + per]
         self.dcoef = torch.tensor(self.coef, dtype=torch.float32, device=self.dev)
         self.hcoef = _ffi.floats(self.coef)
+        if getattr(self, 'ws', None) is not None and self.ws.numel() < max(self.S_loc, 1) * (len(self.coef) + 2):
+            self.ws = torch.empty(max(self.S_loc, 1) * (len(self.coef) + 2), dtype=torch.float32, device=self.dev)
 
     def reset_params(self, new_params, keep_optimizer_state=False):
         """illustrip's per-frame re-parameterisation (illustrip.py:390,411-423) without re-creating anything: the new frame's
@@ -342,6 +354,8 @@ class Engine:
             self._guard_ev = torch.cuda.Event()
             self._guard_ev.record()
         if count > self._guard_seen:
+            # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either
+            self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
             self._guard_seen = count
             self.loss_scale = max(self.loss_scale * 0.5, 1.0)
             self._graphs = None
@@ -352,6 +366,7 @@ class Engine:
         and one or two graph launches).  Everything the kernels read that changes per step -- crop table, augment table,
         Adam scalars -- lives in fixed device buffers refreshed before the replay."""
         torch.cuda.synchronize()
+        self._vit_handle = self.visual.handle
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._enqueue_grad(None)
@@ -389,6 +404,8 @@ class Engine:
         self._upload(hy, table, augs, table2, augs2)
         self._check_overflow()
         use_graph = self.use_graph and shift is None and self.params.is_cuda
+        if self._graphs is not None and self._vit_handle is not self.visual.handle:
+            self._graphs = None          # the ViT handle (and its activation arena) was re-created: the captured pointers are dead
         if use_graph and self._graphs is None and self._calls > 2:      # two eager steps first (one-time kernel attributes, allocator warm-up)
             self._capture()
         if use_graph and self._graphs is not None:

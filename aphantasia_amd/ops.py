@@ -77,6 +77,30 @@ def synth_fft_bwd(plan, d_rgb, rgb, raw, scale, contrast=1.0, colcorr=None, deco
     return out
 
 
+def irfft2(plan, spectrum, out=None, lib=None):
+    """[..,C,H,Wc,2] f32 -> [C,H,W] == torch.fft.irfftn(view_as_complex(x), s=(H,W), norm='ortho') (illustrip.py:401-403)"""
+    L = _L(lib, spectrum)
+    _chk(spectrum, torch.float32, 'spectrum')
+    if spectrum.numel() != plan.C * plan.H * (plan.W // 2 + 1) * 2:
+        raise ValueError('irfft2: %s does not match the plan (%d,%d,%d)' % (tuple(spectrum.shape), plan.C, plan.H, plan.W))
+    if out is None:
+        out = torch.empty(plan.C, plan.H, plan.W, dtype=torch.float32, device=spectrum.device)
+    L.call('aph_irfft2', plan.handle, ptr(spectrum), ptr(out), _stream(spectrum))
+    return out
+
+
+def rfft2(plan, image, out=None, lib=None):
+    """[C,H,W] f32 -> [C,H,Wc,2] == view_as_real(torch.fft.rfftn(x, s=(H,W), dim=[-2,-1], norm='ortho')) (illustrip.py:407-408)"""
+    L = _L(lib, image)
+    _chk(image, torch.float32, 'image')
+    if image.numel() != plan.C * plan.H * plan.W:
+        raise ValueError('rfft2: %s does not match the plan (%d,%d,%d)' % (tuple(image.shape), plan.C, plan.H, plan.W))
+    if out is None:
+        out = torch.empty(plan.C, plan.H, plan.W // 2 + 1, 2, dtype=torch.float32, device=image.device)
+    L.call('aph_rfft2', plan.handle, ptr(image), ptr(out), _stream(image))
+    return out
+
+
 def synth_spatial_fwd(plan, raw, contrast=1.0, fixed_div=0.0, colcorr=None, decorrelate=True, lib=None):
     L = _L(lib, raw)
     _chk(raw, torch.float32, 'raw')
@@ -114,6 +138,13 @@ def sample_out_shape(geom, out_mode):
     return (geom.S, 3, geom.size, geom.size), torch.float32
 
 
+def sample_ws(geom, with_aug, device, lib=None):
+    """caller-owned workspace of one aph_sample_fwd / aph_sample_bwd pair (tap tables + augmentation scratch)"""
+    L = lib if lib is not None else _ffi.lib()
+    n = int(L.cdll.aph_sample_ws_bytes(byref(geom), int(bool(with_aug))))
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+
+
 def sample_fwd(geom, rgb, table, aug=None, tmp=None, out=None, out_mode=_ffi.APH_OUT_NCHW_NORM, lib=None):
     """rgb [3,H,W] f32, table int32 [S,3] (device), aug f32 [S,16] (device) or None"""
     L = _L(lib, rgb, table, aug)
@@ -122,7 +153,7 @@ def sample_fwd(geom, rgb, table, aug=None, tmp=None, out=None, out_mode=_ffi.APH
     if out is None:
         out = torch.empty(shape, dtype=dtype, device=rgb.device)
     if aug is not None and tmp is None:
-        tmp = torch.empty(2 * geom.S * 3 * geom.size * geom.size, dtype=torch.float32, device=rgb.device)
+        tmp = sample_ws(geom, True, rgb.device, L)
     L.call('aph_sample_fwd', byref(geom), ptr(rgb), ptr(table), ptr(aug), ptr(tmp), ptr(out), int(out_mode), _stream(rgb))
     return out
 
@@ -132,8 +163,8 @@ def sample_bwd(geom, gout, table, aug=None, tmp=None, out=None, out_mode=_ffi.AP
     _chk(gout, torch.float32, 'gout')
     if out is None:
         out = torch.empty(3, geom.H, geom.W, dtype=torch.float32, device=gout.device)
-    if aug is not None and tmp is None:
-        tmp = torch.empty(2 * geom.S * 3 * geom.size * geom.size, dtype=torch.float32, device=gout.device)
+    if tmp is None:
+        tmp = sample_ws(geom, aug is not None, gout.device, L)
     L.call('aph_sample_bwd', byref(geom), ptr(gout), float(gscale), ptr(table), ptr(aug), ptr(tmp), ptr(out), int(out_mode),
            _stream(gout))
     return out
@@ -201,7 +232,8 @@ class VitHandle:
 
 
 def gemm_f16(A, Bt, lib=None, tile_cfg=0):
-    """C = A @ Bt^T (f16 in, f32 out); tile_cfg: 0 auto, 1 = 64x64, 2 = 256x128, 3 = 256x256 tiles"""
+    """C = A @ Bt^T (f16 in, f32 out); tile_cfg as in include/aphantasia_hip_test.h: 0 auto, 1 = 64x64, 2 = 256x128,
+    4 = 256x256 phased, 8 / 9 = 64x64 split-K x2 / x4, 10 = 128x128, 22 / 24 = 128x128 split-K x2 / x4"""
     L = _L(lib, A, Bt)
     M, K = A.shape
     N = Bt.shape[0]

@@ -19,34 +19,9 @@ from .transforms import Transform, pack_aug
 def draw_crop_params(count, size, h, w, align='uniform', macro=0., transform=None):
     """The random draws of slice_imgs (utils.py:222-228, 243-247) for one image of size h x w.
     Returns (int32 ndarray [count,3] rows (csize, offx, offy), list of per-cut augment dicts or None).
-    Arithmetic is fp32 and truncating exactly like the reference's 0-dim tensor expressions."""
-    rnd_size = torch.rand(count).numpy()
-    if align == 'central':
-        rnd_offx = torch.clip(torch.randn(count) * 0.2 + 0.5, 0., 1.).numpy()
-        rnd_offy = torch.clip(torch.randn(count) * 0.2 + 0.5, 0., 1.).numpy()
-    else:
-        rnd_offx = torch.rand(count).numpy()
-        rnd_offy = torch.rand(count).numpy()
-    sz_max = min(h, w)
-    ph, pw = h, w
-    if 'over' in align:
-        ph, pw = (2 * h, 2 * w) if align == 'overmax' else (int(1.5 * h), int(1.5 * w))
-    f32 = np.float32
-    big_min = f32(0.9) * f32(sz_max)              # `0.9*sz_max[i]`: python float x int64 0-dim tensor -> fp32
-    geometric = isinstance(transform, Transform) and transform.geometric
-    table = np.empty((count, 3), dtype=np.int32)
-    augs = [] if geometric else None
-    for c in range(count):
-        if f32(torch.rand(1).item()) < f32(macro):      # `torch.rand(1) < macro` compares in fp32
-            csize = int(rnd_size[c] * (f32(sz_max) - big_min) + big_min)
-        else:
-            csize = int(rnd_size[c] * f32(sz_max - size) + f32(size))
-        table[c, 0] = csize
-        table[c, 1] = int(rnd_offx[c] * f32(pw - csize))
-        table[c, 2] = int(rnd_offy[c] * f32(ph - csize))
-        if geometric:
-            augs.append(transform.draw(size))     # where the reference calls transform(cut), utils.py:251
-    return table, augs
+    Arithmetic is fp32 and truncating exactly like the reference's 0-dim tensor expressions
+    (`0.9*sz_max[i]` is python float x int64 0-dim tensor -> fp32; `torch.rand(1) < macro` compares in fp32)."""
+    return draw_crop_params_multi(count, size, [(h, w)], align, macro, transform)[0]
 
 
 def draw_crop_params_bulk(count, size, h, w, align, macro, transform, rng):
@@ -84,9 +59,7 @@ class _Slice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, geom, table, aug, out_mode):
         rgb = img.reshape(3, geom.H, geom.W).contiguous().float()
-        tmp = None
-        if aug is not None:
-            tmp = torch.empty(2 * geom.S * 3 * geom.size * geom.size, dtype=torch.float32, device=rgb.device)
+        tmp = ops.sample_ws(geom, aug is not None, rgb.device)
         out = ops.sample_fwd(geom, rgb, table, aug, tmp, None, out_mode)
         ctx.geom, ctx.out_mode, ctx.tmp = geom, out_mode, tmp
         ctx.save_for_backward(table, aug if aug is not None else table)
@@ -101,34 +74,65 @@ class _Slice(torch.autograd.Function):
         return d.reshape(ctx.shape), None, None, None, None
 
 
+def draw_crop_params_multi(count, size, hw_list, align='uniform', macro=0., transform=None):
+    """slice_imgs' draws for a LIST of images (utils.py:222-228 once, then utils.py:238-253 per image): the size / offset
+    vectors are drawn once and shared by every image; the per-cut macro draw and the transform's draws repeat per image, in
+    image order.  -> list of (table, augs), one per image."""
+    rnd_size = torch.rand(count).numpy()
+    if align == 'central':
+        rnd_offx = torch.clip(torch.randn(count) * 0.2 + 0.5, 0., 1.).numpy()
+        rnd_offy = torch.clip(torch.randn(count) * 0.2 + 0.5, 0., 1.).numpy()
+    else:
+        rnd_offx = torch.rand(count).numpy()
+        rnd_offy = torch.rand(count).numpy()
+    f32 = np.float32
+    geometric = isinstance(transform, Transform) and transform.geometric
+    out = []
+    for (h, w) in hw_list:
+        sz_max = min(h, w)
+        ph, pw = h, w
+        if 'over' in align:
+            ph, pw = (2 * h, 2 * w) if align == 'overmax' else (int(1.5 * h), int(1.5 * w))
+        big_min = f32(0.9) * f32(sz_max)
+        table = np.empty((count, 3), dtype=np.int32)
+        augs = [] if geometric else None
+        for c in range(count):
+            if f32(torch.rand(1).item()) < f32(macro):
+                csize = int(rnd_size[c] * (f32(sz_max) - big_min) + big_min)
+            else:
+                csize = int(rnd_size[c] * f32(sz_max - size) + f32(size))
+            table[c, 0] = csize
+            table[c, 1] = int(rnd_offx[c] * f32(pw - csize))
+            table[c, 2] = int(rnd_offy[c] * f32(ph - csize))
+            if geometric:
+                augs.append(transform.draw(size))
+        out.append((table, augs))
+    return out
+
+
 def slice_imgs(imgs, count, size=224, transform=None, align='uniform', macro=0., patch=32):
     """utils.py:218-254.  imgs: list of [1,3,H,W] CUDA tensors -> list of [count,3,size,size] tensors.
     transform: None, aphantasia_amd.transforms.normalize(), transforms_fast (fused in the HIP sampler),
     or any other callable (applied per cut on the un-normalised crops, like upstream)."""
-    sliced = []
-    tables = []
     for img in imgs:
         if img.dim() != 4 or img.shape[0] != 1 or img.shape[1] != 3:
             raise ValueError('slice_imgs expects [1,3,H,W] images, got %s' % (tuple(img.shape),))
-        h, w = img.shape[2:]
-        tables.append((h, w))
-    # the reference draws the size/offset vectors once for all images and the per-cut draws per image
-    if len(imgs) != 1:
-        raise NotImplementedError('slice_imgs: one image per call (all call sites in clip_fft.py pass one)')
-    img = imgs[0]
-    h, w = tables[0]
     fused = transform is None or isinstance(transform, Transform)
-    table, augs = draw_crop_params(count, size, h, w, align, macro, transform if fused else None)
-    geom = ops.make_geom(h, w, count, size, patch if size % patch == 0 else 1, align)
-    dev = img.device
-    tb = torch.from_numpy(table).to(dev)
-    aug = pack_aug(augs).to(dev) if augs is not None else None
-    if fused:
-        mode = _ffi.APH_OUT_NCHW_RAW if transform is None or not transform.normalise else _ffi.APH_OUT_NCHW_NORM
-        sliced.append(_Slice.apply(img, geom, tb, aug, mode))
-    else:
-        raw = _Slice.apply(img, geom, tb, None, _ffi.APH_OUT_NCHW_RAW)
-        sliced.append(torch.cat([transform(raw[c:c + 1]) for c in range(count)], 0))
+    # the reference draws the size / offset vectors once for all images and the per-cut draws image by image (utils.py:222-253)
+    draws = draw_crop_params_multi(count, size, [tuple(img.shape[2:]) for img in imgs], align, macro, transform if fused else None)
+    sliced = []
+    for img, (table, augs) in zip(imgs, draws):
+        h, w = img.shape[2:]
+        geom = ops.make_geom(h, w, count, size, patch if size % patch == 0 else 1, align)
+        dev = img.device
+        tb = torch.from_numpy(table).to(dev)
+        aug = pack_aug(augs).to(dev) if augs is not None else None
+        if fused:
+            mode = _ffi.APH_OUT_NCHW_RAW if transform is None or not transform.normalise else _ffi.APH_OUT_NCHW_NORM
+            sliced.append(_Slice.apply(img, geom, tb, aug, mode))
+        else:
+            raw = _Slice.apply(img, geom, tb, None, _ffi.APH_OUT_NCHW_RAW)
+            sliced.append(torch.cat([transform(raw[c:c + 1]) for c in range(count)], 0))
     return sliced
 
 

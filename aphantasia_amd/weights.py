@@ -84,3 +84,46 @@ def load_openai_checkpoint(path):
     cfg = dict(input_resolution=grid * p, patch_size=p, width=width, layers=layers,
                heads=width // 64, output_dim=vis['proj'].shape[1])
     return vis, cfg, sd
+
+
+def stress_visual_weights(cfg, seed=1):
+    """Synthetic weights with the activation statistics real CLIP towers are known for, which the unit-gain
+    initialisation above never produces: LayerNorm gains spread over [0.2, 10] with non-zero biases (the linear
+    that follows is scaled down column-wise, so the block's output keeps order-1 magnitude while the fp16
+    intermediate spans a wide range), a few residual-stream channels carrying 50-100x the typical magnitude
+    ("massive activations": written by the class/positional embeddings and by every c_proj bias), and non-zero
+    attention biases.  Same key layout as synthetic_visual_weights.  Used by the stress parity tests and by
+    anyone without a checkpoint who wants realistic dynamic range; APH_CLIP_CHECKPOINT (a real OpenAI archive)
+    takes precedence in those tests when it is set."""
+    w = synthetic_visual_weights(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    width, layers = cfg['width'], cfg['layers']
+    outliers = torch.randperm(width, generator=g)[:3]
+
+    def gains():
+        gn = torch.exp(torch.empty(width).uniform_(math.log(0.2), math.log(10.0), generator=g))
+        gn[outliers] = torch.empty(3).uniform_(0.05, 0.2, generator=g)      # real towers damp the massive channels in the LN gain
+        return gn
+
+    w['class_embedding'][outliers] += torch.tensor([60.0, -80.0, 100.0]) * width ** -0.5 * 8
+    w['positional_embedding'][:, outliers] += (torch.randn(w['positional_embedding'].shape[0], 3, generator=g) * 0.5 + 2.0) * torch.tensor([1.0, -1.0, 1.0])
+    for name in ('ln_pre',):
+        w[name + '.weight'] = torch.exp(torch.empty(width).uniform_(math.log(0.5), math.log(2.0), generator=g))
+        w[name + '.bias'] = 0.1 * torch.randn(width, generator=g)
+    for i in range(layers):
+        pre = 'transformer.resblocks.%d.' % i
+        for ln, lin in (('ln_1', 'attn.in_proj_weight'), ('ln_2', 'mlp.c_fc.weight')):
+            gn = gains()
+            w[pre + ln + '.weight'] = gn
+            w[pre + ln + '.bias'] = 0.3 * torch.randn(width, generator=g) * gn
+            w[pre + lin] = w[pre + lin] / gn[None, :]                       # wide fp16 range in h, order-1 products
+        w[pre + 'attn.in_proj_weight'][:2 * width] *= 2.5                    # peaky softmax (logits up to ~15) instead of near-uniform attention
+        w[pre + 'attn.in_proj_bias'] = 0.2 * torch.randn(3 * width, generator=g)
+        w[pre + 'attn.out_proj.bias'] = 0.05 * torch.randn(width, generator=g)
+        # massive residual channels: every MLP adds a large constant to three channels
+        w[pre + 'mlp.c_proj.bias'][outliers] += torch.tensor([6.0, -8.0, 10.0]) * (1.0 if i < layers // 2 else 0.2)
+    gn = torch.exp(torch.empty(width).uniform_(math.log(0.5), math.log(4.0), generator=g))
+    w['ln_post.weight'] = gn
+    w['ln_post.bias'] = 0.1 * torch.randn(width, generator=g)
+    w['proj'] = w['proj'] / gn[:, None] * 2.0
+    return w

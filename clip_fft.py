@@ -76,6 +76,11 @@ def get_args(argv=None):
     parser.add_argument(       '--clip-weights2', dest='clip_weights2', default=None, help='checkpoint of the --dualmod model (ViT-B-16.pt)')
     parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
     parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
+    parser.add_argument(       '--rng',     default=None, choices=['bulk', 'reference'], help="host random draws: 'reference' = the reference's exact draw "
+                               "order on torch's / numpy's global generators (a seeded run reproduces the reference's crop and augment tables); "
+                               "'bulk' = vectorised draws from a numpy Generator (same distributions, a different stream, ~10x less host time). "
+                               "Default: reference when --seed is given, else bulk")
+    parser.add_argument(       '--ranks',   default=1, type=int, help='GPUs of this node to shard the cuts over (launch with torchrun, or let this flag spawn the ranks)')
     a = parser.parse_args(argv)
 
     if a.size is not None: a.size = [int(s) for s in a.size.split('-')][::-1]        # clip_fft.py:80
@@ -86,6 +91,8 @@ def get_args(argv=None):
     if a.dualmod is not None:                                                         # clip_fft.py:86-88
         a.model = 'ViT-B/32'
         a.sim = 'cossim'
+    if a.rng is None:
+        a.rng = 'reference' if a.seed is not None else 'bulk'
     return a
 
 
@@ -257,15 +264,16 @@ def main(argv=None):
         pk = dict(param_kind='fft')
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, **pk)
+                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, **pk)
+                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
-    gamma = 1.0
+    # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp
+    gamma = 1.3 if (a.sync > 0 and a.in_img is not None) else (1 + a.sharp / 2. if a.sharp != 0 else 1.0)
     t0 = time.time()
     for i in range(a.steps):
         e = eng2 if (eng2 is not None and i in dualmod_nums) else eng

@@ -47,6 +47,12 @@ int aph_synth_fft_fwd(aph_synth_plan* plan, const float* d_params, const float* 
 int aph_synth_fft_bwd(aph_synth_plan* plan, const float* d_rgb_grad, float gscale, const float* d_rgb, const float* d_raw,
                       const float* d_scale, float contrast, const float* colcorr_t9, int decorrelate,
                       float* d_grad_params, void* stream);
+/* The two transforms alone, torch.fft semantics with norm='ortho' on the plan's geometry -- illustrip.py:401-409, the
+ * per-frame `irfftn -> frame_transform -> rfftn` round trip of `--gen FFT`:
+ *   aph_irfft2: d_spectrum [C,H,W/2+1,2] -> d_image [C,H,W]   == torch.fft.irfftn(view_as_complex(x), s=(H,W), norm='ortho')
+ *   aph_rfft2:  d_image [C,H,W] -> d_spectrum [C,H,W/2+1,2]   == view_as_real(torch.fft.rfftn(x, s=(H,W), dim=[2,3], norm='ortho')) */
+int aph_irfft2(aph_synth_plan* plan, const float* d_spectrum, float* d_image, void* stream);
+int aph_rfft2(aph_synth_plan* plan, const float* d_image, float* d_spectrum, void* stream);
 /* to_valid_rgb(pixel_image(...)) (image.py:114-118) and the post-inverse-DWT part of dwt_image (image.py:68):
  * raw -> raw*contrast/std (or /fixed_div when fixed_div > 0) -> colour mix -> sigmoid */
 int aph_synth_spatial_fwd(aph_synth_plan* plan, const float* d_raw, float contrast, float fixed_div,
@@ -102,16 +108,20 @@ typedef struct aph_sample_geom {
 /* per-cut augment row (f32 x 16): [0..7] perspective coeffs, [8] has_perspective, [9..12] erase i,j,h,w
  * (h=0: none), [13] cos(angle), [14] sin(angle), [15] has_rotation (transforms_fast always 1) */
 
+/* bytes of the caller-owned device workspace d_ws of one forward/backward pair on geometry g (per-cut tap tables of the
+ * crop adjoint; with_aug != 0 adds the cut scratch of the geometric augmentations).  The library never allocates in a
+ * launch path, so the calls can be captured into a hipGraph that stays valid as long as the caller's buffers do. */
+size_t aph_sample_ws_bytes(const aph_sample_geom* g, int with_aug);
 /* d_rgb [3,H,W] f32; d_table int32 [S,3] rows (csize, offx, offy) (utils.py:245-247);
- * d_aug f32 [S,16] or NULL (no geometric augmentation); d_tmp: f32 scratch of 2*S*3*size*size
- * elements, only needed when d_aug != NULL.  out layout per out_mode. */
+ * d_aug f32 [S,16] or NULL (no geometric augmentation); d_ws: see aph_sample_ws_bytes (may be NULL
+ * when d_aug == NULL).  out layout per out_mode. */
 int aph_sample_fwd(const aph_sample_geom* g, const float* d_rgb, const int32_t* d_table, const float* d_aug,
-                   float* d_tmp, void* d_out, int out_mode, void* stream);
+                   void* d_ws, void* d_out, int out_mode, void* stream);
 /* adjoint.  d_out_grad: f32 in the layout of out_mode (patch-major f32 for APH_OUT_PATCH_F16; patch-major f16 for
- * APH_GRAD_PATCH_F16), multiplied by gscale.  d_tmp as above (overwritten).
+ * APH_GRAD_PATCH_F16), multiplied by gscale.  d_ws as above (required, overwritten).
  * Writes (does not accumulate) d_rgb_grad [3,H,W]. */
 int aph_sample_bwd(const aph_sample_geom* g, const void* d_out_grad, float gscale, const int32_t* d_table,
-                   const float* d_aug, float* d_tmp, float* d_rgb_grad, int out_mode, void* stream);
+                   const float* d_aug, void* d_ws, float* d_rgb_grad, int out_mode, void* stream);
 /* illustrip.py:130-138 frame_transform = T.functional.affine(img, angle, shift, scale, shear, fill=0, BILINEAR) of a whole
  * [C,H,W] image (once per frame).  h_inv_matrix6: HOST pointer, row-major 2x3 inverse affine matrix (torchvision's
  * _get_inverse_affine_matrix with the image centre as origin).  d_dst must not alias d_src. */
@@ -137,14 +147,7 @@ int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_gr
 /* same with the patch gradient stored as f16 (keep the loss scale in it: out_scale = 1, and undo it in aph_sample_bwd's
  * gscale with out_mode APH_GRAD_PATCH_F16): halves the bytes the sampler adjoint gathers */
 int aph_vit_backward_h(aph_vit* vit, const float* d_genc, int S, void* d_patch_grad_f16, float out_scale, void* stream);
-/* per-launch HIP-event timing of the ViT's GEMM launches (bench.py roofline): on/off, then read the sums */
-int aph_vit_profile(aph_vit* vit, int on);
-int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
-/* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core, exported for tests */
-int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
-/* same with explicit row pitches and tile configuration (0 auto, 1 = 64x64, 2 = 256x128, 3 = 256x256): unit tests */
-int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
-                    void* stream);
+/* (test / measurement hooks -- GEMM core alone, per-launch GEMM timing -- are declared in aphantasia_hip_test.h) */
 
 /* ---- loss: aphantasia/utils.py:270-295 sim_func, assembled as at clip_fft.py:257-267 -------- */
 #define APH_SIM_COS 0   /* type None / 'cossim' */

@@ -1,0 +1,31 @@
+/* libaphantasia_hip.so -- test and measurement hooks.  NOT part of the drop-in boundary (include/aphantasia_hip.h):
+ * nothing a reference-side binding needs is declared here.  Used by tests/ (GEMM core alone, every tile
+ * configuration) and by bench.py's roofline leg (per-launch GEMM timing on the launch stream).
+ */
+#ifndef APHANTASIA_HIP_TEST_H
+#define APHANTASIA_HIP_TEST_H
+
+#include "aphantasia_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-launch HIP-event timing of the ViT's GEMM launches (bench.py roofline): on/off, then read the sums */
+int aph_vit_profile(aph_vit* vit, int on);
+int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
+/* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core with the automatic tile choice */
+int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
+/* same with explicit row pitches (elements, multiples of 8) and an explicit tile configuration:
+ *    0  automatic (the shape heuristic of launch_gemm)
+ *    1  64x64, 4 waves            2  256x128, 8 waves, 3-stage ring       4  256x256 phased (needs N % 256 == 0)
+ *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
+ *   22 / 24  128x128 split-K x2 / x4
+ * any other value is rejected (APH_ERR_ARG). */
+int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

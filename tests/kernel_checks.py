@@ -59,6 +59,22 @@ def check_synth_vs_oracle(lib, dev, h, w, contrast=1.0, with_shift=False):
     assert (grad.cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
 
 
+def check_fft_pair(lib, dev, h, w):
+    """aph_irfft2 / aph_rfft2 == torch.fft.irfftn / rfftn with norm='ortho' (illustrip.py:401-409), and the round trip"""
+    seed_all(6)
+    plan = ops.SynthPlan(3, h, w, lib=lib)
+    spec = torch.randn(1, 3, h, w // 2 + 1, 2)
+    want = torch.fft.irfftn(torch.view_as_complex(spec), s=(h, w), norm='ortho')
+    got = ops.irfft2(plan, spec.to(dev).contiguous(), lib=lib)
+    assert (got.cpu() - want[0]).abs().max().item() < 2e-5 * want.abs().max().item()
+    img = torch.randn(1, 3, h, w)
+    wants = torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho'))
+    gots = ops.rfft2(plan, img[0].to(dev).contiguous(), lib=lib)
+    assert (gots.cpu() - wants[0]).abs().max().item() < 2e-5 * wants.abs().max().item()
+    back = ops.irfft2(plan, gots, lib=lib)
+    assert (back.cpu() - img[0]).abs().max().item() < 2e-5 * img.abs().max().item()
+
+
 def check_synth_spatial(lib, dev, h=24, w=40):
     seed_all(2)
     cc_t = R.colcorr_t(1.8)
@@ -151,6 +167,55 @@ def check_sampler_augment(lib, dev, H=40, W=48, S=6, size=16, patch=8):
     assert (out.cpu() - cuts.detach()).abs().max().item() < 3e-4
     got = ops.sample_bwd(geom, gout.to(dev).contiguous(), tb, aug=aug, lib=lib)
     assert (got.cpu() - img.grad[0]).abs().max().item() < 3e-4 * img.grad.abs().max().item()
+
+
+def check_augment_invariants(lib, dev, size=32, patch=16):
+    """Properties the real torchvision ops satisfy (transforms.py:165-170), checked on the HIP sampler: a-8 stays
+    "parity unpinned" (no torchvision in the image) -- these pin what can be pinned without it."""
+    seed_all(12)
+    H, W, S = 48, 64, 6
+    img = torch.rand(1, 3, H, W)
+    table = R.draw_crop_table(S, size, H, W, 'uniform', 0.4)
+    geom = ops.make_geom(H, W, S, size, patch=patch)
+    tb = torch.from_numpy(table).to(dev)
+    rgb = img[0].to(dev).contiguous()
+    plain = ops.sample_fwd(geom, rgb, tb, lib=lib).cpu()                       # normalize()-only path (parity pinned by the goldens)
+    start = [[0, 0], [size - 1, 0], [size - 1, size - 1], [0, size - 1]]
+    ident = augment_ref.perspective_coeffs(start, start)
+    assert np.allclose(ident, [1, 0, 0, 0, 1, 0, 0, 0], atol=1e-6)             # endpoints == startpoints -> identity homography
+    # (1) nothing drawn: no perspective, no erase, 0 degrees.  torchvision's affine has no identity shortcut: the 0-degree
+    #     grid still goes through grid_sample, whose fp32 unnormalisation lands within ~1e-5 px of the pixel centres, so the
+    #     result equals the normalize-only cuts to rounding (not bit for bit); the ones-mask is 1 to the same rounding.
+    prm0 = [dict(persp=None, erase=None, angle=0.0) for _ in range(S)]
+    out0 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm0).to(dev), lib=lib).cpu()
+    assert (out0 - plain).abs().max().item() < 5e-5
+    # (2) identity perspective + 0 degrees: same
+    prm1 = [dict(persp=ident, erase=None, angle=0.0) for _ in range(S)]
+    out1 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm1).to(dev), lib=lib).cpu()
+    assert (out1 - plain).abs().max().item() < 1e-4
+    # (3) erase: the rectangle [i, i+h) x [j, j+w) is 0 BEFORE normalisation, i.e. -mean/std after; everything else untouched
+    rect = (3, 5, 7, 9)
+    prm2 = [dict(persp=None, erase=rect, angle=None) for _ in range(S)]          # angle None: no rotation stage at all (has_rotation 0)
+    out2 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm2).to(dev), lib=lib).cpu()
+    zero = R.normalize(torch.zeros(1, 3, 1, 1))
+    i, j, eh, ew = rect
+    assert torch.allclose(out2[:, :, i:i + eh, j:j + ew], zero.expand(S, 3, eh, ew), atol=1e-6)
+    keep = torch.ones(size, size, dtype=torch.bool); keep[i:i + eh, j:j + ew] = False
+    assert torch.equal(out2[:, :, keep], plain[:, :, keep])
+    # (4) a pure-translation homography (endpoints = startpoints + t) moves the content by +t; pixels whose source falls
+    #     outside the cut are exactly the fill (0 before normalisation): the ones-mask blend
+    t = (4, 3)
+    end = [[x + t[0], y + t[1]] for x, y in start]
+    prm3 = [dict(persp=augment_ref.perspective_coeffs(start, end), erase=None, angle=None) for _ in range(S)]
+    out3 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm3).to(dev), lib=lib).cpu()
+    assert (out3[:, :, t[1]:, t[0]:] - plain[:, :, :size - t[1], :size - t[0]]).abs().max().item() < 2e-4
+    assert torch.allclose(out3[:, :, :t[1] - 1, :], zero.expand(S, 3, t[1] - 1, size), atol=1e-6)
+    assert torch.allclose(out3[:, :, :, :t[0] - 1], zero.expand(S, 3, size, t[0] - 1), atol=1e-6)
+    # (5) +90 degrees: T.functional.affine rotates CLOCKWISE (its inverse matrix [[cos, sin], [-sin, cos]] maps an output pixel
+    #     right of the centre to the input pixel above it), exactly a transpose + flip on a square cut
+    prm4 = [dict(persp=None, erase=None, angle=90.0) for _ in range(S)]
+    out4 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm4).to(dev), lib=lib).cpu()
+    assert (out4 - torch.rot90(plain, k=-1, dims=(2, 3))).abs().max().item() < 2e-4
 
 
 def check_sim_loss(lib, dev, g):

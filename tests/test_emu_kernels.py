@@ -35,6 +35,11 @@ def test_dwt(emu):
     K.check_dwt(emu, 'cpu', 'coif2', 64, 96)
 
 
+def test_fft_pair(emu):
+    K.check_fft_pair(emu, 'cpu', 24, 40)
+    K.check_fft_pair(emu, 'cpu', 21, 27)
+
+
 def test_synth_spatial(emu):
     K.check_synth_spatial(emu, 'cpu')
 
@@ -52,6 +57,10 @@ def test_sampler_adjoint(emu, align, mode):
 
 def test_sampler_augment(emu):
     K.check_sampler_augment(emu, 'cpu')
+
+
+def test_augment_invariants(emu):
+    K.check_augment_invariants(emu, 'cpu')
 
 
 def test_sim_loss(emu, golden):

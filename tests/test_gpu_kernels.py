@@ -24,6 +24,12 @@ def test_synth_oracle_full_size():
     K.check_synth_vs_oracle(None, DEV, 720, 1280, 1.0)
 
 
+def test_fft_pair():
+    K.check_fft_pair(None, DEV, 24, 40)
+    K.check_fft_pair(None, DEV, 45, 63)
+    K.check_fft_pair(None, DEV, 720, 1280)
+
+
 def test_dwt():
     K.check_dwt(None, DEV, 'db3', 45, 70)
     K.check_dwt(None, DEV, 'coif2', 64, 96)
@@ -55,6 +61,11 @@ def test_sampler_adjoint_full_size():
 def test_sampler_augment():
     K.check_sampler_augment(None, DEV)
     K.check_sampler_augment(None, DEV, H=360, W=640, S=12, size=224, patch=32)
+
+
+def test_augment_invariants():
+    K.check_augment_invariants(None, DEV)
+    K.check_augment_invariants(None, DEV, size=224, patch=32)
 
 
 def test_sim_loss(golden):

@@ -1,0 +1,383 @@
+"""GPU (MI355X): parity of the HIP path with the CPU oracle AT BASELINE.json's configurations:
+C2 one full 1280x720 / 200-cut step and a 1280x720 loss curve, the C3 two-model `-dm` schedule on a shared Adam state,
+the C4 3840x2160 db3 inverse DWT and its adjoint, a "stress" ViT weight set with realistic dynamic range, and the
+optional loss terms (--sharp / --expand / --enforce, illustrip's RGB priors and per-frame re-parameterisation) against
+the oracle's restatement of clip_fft.py:235-295 / illustrip.py:381-470 rather than against the drop-in API.
+
+The oracle legs cost tens of seconds of host CPU each (the GPU box has 128 cores); everything goes through the C ABI.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from aphantasia_amd import transforms
+from aphantasia_amd.engine import Engine
+from aphantasia_amd.utils import draw_crop_params
+from aphantasia_amd.weights import stress_visual_weights, visual_config
+from oracle import reference_path as R
+from oracle import augment_ref, clip_vit_ref
+import kernel_checks as K
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def load(name, max_batch, weights=None):
+    from aphantasia_amd import clip as aclip
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m, _ = aclip.load(name, seed=1, max_batch=max_batch)
+    if weights is not None:
+        m = aclip.CLIPModel(name, visual_config(name), weights, None, max_batch)
+    return m
+
+
+@pytest.fixture(scope='module')
+def b32():
+    return load('ViT-B/32', 200)
+
+
+@pytest.fixture(scope='module')
+def b16():
+    return load('ViT-B/16', 48)
+
+
+def oracle_encoder(model):
+    cfg, wts = model.visual.cfg, model.visual.weights
+    return lambda x: clip_vit_ref.encode_image(wts, x, cfg)
+
+
+def per_cut_of(augs):
+    """per-cut transform of the oracle's slice_imgs from the product's host-drawn augment dicts (None -> normalize only)"""
+    if augs is None:
+        return None
+    return lambda c, cut: augment_ref.apply_fast(cut, augs[c], R.normalize)
+
+
+def target512(seed=2):
+    return torch.randn(1, 512, generator=torch.Generator().manual_seed(seed))
+
+
+def compare_grad(got, ref, cos_min, rel_max):
+    got, ref = got.reshape(-1).float().cpu(), ref.reshape(-1).float()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=0).item()
+    rel = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert cos > cos_min and rel < rel_max, (cos, rel)
+    return cos, rel
+
+
+# ------------------------------------------------------------------------------------------------ C2
+def test_c2_full_step_vs_oracle(b32):
+    """configs[1]: 1280x720 FFT, ViT-B/32, 200 cuts (-tf none), the reference's own draw order: loss, spectrum gradient
+    and the parameters after Adam against ReferenceRun.step (clip_fft.py:235-295)."""
+    h, w, S = 720, 1280, 200
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], sim='mix', transform=transforms.normalize(), rng='reference', use_graph=False)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0)
+    seed_all(11)
+    table, _ = draw_crop_params(S, 224, h, w, 'uniform', 0.4, transforms.normalize())
+    seed_all(11)
+    assert np.array_equal(table, R.draw_crop_table(S, 224, h, w, 'uniform', 0.4))      # host draws == the oracle's restated order
+    got = float(eng.step(table))
+    want = run.step(table)
+    assert abs(got - want) < 1e-3, (got, want)
+    cos, rel = compare_grad(eng.grad, run.params.grad, 0.9995, 3e-2)
+    dp = (eng.params.cpu().reshape(-1) - run.params_flat()).abs()
+    # Adam with b1 = 0 moves every coordinate by lr * sign-ish; a coordinate whose tiny gradient flips sign under fp16 moves 2 lr
+    frac_off = (dp > 0.02).float().mean().item()
+    print('C2 one step: loss %.6f vs %.6f, grad cos %.6f, max rel %.2e, mean |dparam| %.2e, frac(|dparam| > .02) %.2e'
+          % (got, want, cos, rel, dp.mean().item(), frac_off))
+    assert dp.mean().item() < 2e-3 and frac_off < 2e-2
+
+
+def test_c2_loss_curve_720p_32cuts(b32):
+    """1280x720, 32 cuts, 10 free-running Adam steps: per-step |d loss| <= 1e-3 (north_star tolerance), final-image RMS"""
+    h, w, S, steps = 720, 1280, 32, 10
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], sim='mix', transform=transforms.normalize(), rng='reference')
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0)
+    seed_all(9)
+    worst = 0.0
+    for i in range(steps):
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got, want = float(eng.step(table)), run.step(table)
+        worst = max(worst, abs(got - want))
+        assert abs(got - want) < 1e-3, (i, got, want)
+    with torch.no_grad():
+        rms = (eng.synthesize(1.1).cpu() - run.image(1.1)[0]).pow(2).mean().sqrt().item()
+    print('720p / 32 cuts loss curve: max |d loss| %.2e over %d steps, final pixel RMS %.4f' % (worst, steps, rms))
+    assert rms < 0.02
+
+
+def test_c2_fast_transform_step_vs_oracle(b32):
+    """the default `-tf fast` path at 1280x720 (24 cuts): perspective / erase / rotate drawn in the reference's order, one
+    step against the oracle's restated torchvision ops (parity of those ops themselves is unpinned: no torchvision here)"""
+    h, w, S = 720, 1280, 24
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], sim='mix', transform=transforms.transforms_fast, rng='reference', use_graph=False)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0)
+    seed_all(4)
+    table, augs = draw_crop_params(S, 224, h, w, 'uniform', 0.4, transforms.transforms_fast)
+    assert sum(a['persp'] is not None for a in augs) >= 2 and sum(a['erase'] is not None for a in augs) >= 2 and sum(a['angle'] != 0 for a in augs) >= 8
+    got = float(eng.step(table, augs))
+    want = run.step(table, per_cut_of(augs))
+    assert abs(got - want) < 1e-3, (got, want)
+    cos, rel = compare_grad(eng.grad, run.params.grad, 0.999, 5e-2)
+    print('C2 -tf fast one step: loss %.6f vs %.6f, grad cos %.6f, max rel %.2e' % (got, want, cos, rel))
+
+
+# ------------------------------------------------------------------------------------------------ C3
+def test_c3_dual_model_schedule_vs_oracle(b32, b16):
+    """configs[2] on one rank: `-dm 2` -> steps 2, 4 use ViT-B/16 with its own text embedding, the others ViT-B/32; ONE Adam
+    state (clip_fft.py:132-136, 243-252); 43 cuts (200 -> x0.23 -> x0.95), sim forced to cossim (clip_fft.py:88)."""
+    h, w, S, steps, dm = 720, 1280, 43, 6, 2
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    t1, t2 = target512(2), target512(3)
+    leaf = p0.to(DEV).contiguous()
+    kw = dict(sim='cossim', transform=transforms.normalize(), rng='reference')
+    eng1 = Engine(leaf, h, w, b32, S, [(t1, -1.0)], **kw)
+    eng2 = Engine(leaf, h, w, b16, S, [(t2, -1.0)], state=eng1.state(), **kw)
+    run = R.ReferenceRun(h, w, None, None, sim='cossim', params=p0,
+                         models=[(oracle_encoder(b32), [(t1, 1.0)]), (oracle_encoder(b16), [(t2, 1.0)])])
+    dualmod_nums = list(range(steps))[dm::dm]
+    assert dualmod_nums == [2, 4]
+    seed_all(21)
+    worst = 0.0
+    for i in range(steps):
+        k = 1 if i in dualmod_nums else 0
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got = float((eng2 if k else eng1).step(table))
+        want = run.step(table, model=k)
+        worst = max(worst, abs(got - want))
+        assert abs(got - want) < 1e-3, (i, k, got, want)
+    assert eng1.step_count == steps and eng2.step_count == steps            # one shared step counter / moment buffers
+    assert eng1.v.data_ptr() == eng2.v.data_ptr()
+    with torch.no_grad():
+        rms = (eng1.synthesize(1.1).cpu() - run.image(1.1)[0]).pow(2).mean().sqrt().item()
+    print('C3 -dm 2, %d steps: max |d loss| %.2e, final pixel RMS %.4f' % (steps, worst, rms))
+    assert rms < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ C4
+def test_c4_irdwt_full_size_vs_oracle():
+    """configs[3]: the 3840x2160 db3 inverse DWT (11 levels, 25 M coefficients) + colour / sigmoid and the full adjoint vs
+    oracle/dwt_ref.py (pinned to PyWavelets 1.1.1)"""
+    K.check_dwt(None, DEV, 'db3', 2160, 3840)
+
+
+def test_c4_step_vs_oracle(b16):
+    """one DWT-parameterised step through ViT-B/16 at a reduced frame (the CPU oracle of the full C4 step is minutes):
+    960x540 db3, 12 cuts, loss + coefficient gradient"""
+    from aphantasia_amd.image import dwt_image
+    from oracle import dwt_ref
+    h, w, S = 540, 960, 12
+    seed_all(0)
+    params, image_f, _ = dwt_image([1, 3, h, w], 'db3', 0.3, 1.8, None)
+    Ys = [p.detach().cpu().clone() for p in params]
+    tgt = target512()
+    eng = Engine(image_f.flat.detach().clone(), h, w, b16, S, [(tgt, -1.0)], transform=transforms.normalize(), param_kind='dwt',
+                 dwt=image_f.synth, rng='reference', use_graph=False)
+    run = R.ReferenceRun(eng.h, eng.w, oracle_encoder(b16), [(tgt, 1.0)], params=Ys, param_kind='dwt', wave='db3', dwt_sharp=0.3)
+    assert tuple(run.image().shape[2:]) == (eng.h, eng.w)
+    seed_all(5)
+    table = R.draw_crop_table(S, 224, eng.h, eng.w, 'uniform', 0.4)
+    got, want = float(eng.step(table)), run.step(table)
+    assert abs(got - want) < 1e-3, (got, want)
+    cos, rel = compare_grad(eng.grad, run.grad_flat(), 0.999, 5e-2)
+    print('DWT step (ViT-B/16): loss %.6f vs %.6f, grad cos %.6f, max rel %.2e' % (got, want, cos, rel))
+
+
+# ------------------------------------------------------------------------------------------------ stress weights
+def stress_model(name, max_batch):
+    ck = os.environ.get('APH_CLIP_CHECKPOINT')
+    if ck and os.path.isfile(ck):               # a real OpenAI archive, when the user has one
+        from aphantasia_amd import clip as aclip
+        return aclip.load(name, weights=ck, max_batch=max_batch)[0], 'checkpoint ' + ck
+    return load(name, max_batch, stress_visual_weights(visual_config(name), 1)), 'stress_visual_weights'
+
+
+@pytest.mark.parametrize('name', ['ViT-B/32', 'ViT-B/16'])
+def test_vit_stress_weights(name):
+    """ViT forward / input-gradient with LN gains in [0.2, 10], residual channels at 50-100x the median and peaky attention
+    (or a real checkpoint through APH_CLIP_CHECKPOINT): embedding and gradient cosine + relative error vs the fp32 oracle"""
+    from aphantasia_amd import ops
+    model, src = stress_model(name, 4)
+    cfg, w = model.visual.cfg, model.visual.weights
+    S, Rr, p = 3, cfg['input_resolution'], cfg['patch_size']
+    x = torch.randn(S, 3, Rr, Rr, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    want = clip_vit_ref.encode_image(w, x, cfg)
+    genc = torch.randn(S, cfg['output_dim'], generator=torch.Generator().manual_seed(2)) * 0.01
+    (want * genc).sum().backward()
+    vit = model.visual.handle
+    enc = vit.forward(ops.patchify(x.detach().to(DEV).contiguous(), p), S)
+    ecos = torch.nn.functional.cosine_similarity(enc.cpu(), want.detach(), dim=-1).min().item()
+    ferr = (enc.cpu() - want.detach()).abs().max().item() / want.abs().max().item()
+    from aphantasia_amd.clip import LOSS_SCALE
+    gp = vit.backward((genc * LOSS_SCALE).to(DEV).contiguous(), S, out_scale=1.0 / LOSS_SCALE)
+    gx = ops.unpatchify(gp, S, Rr, p).cpu()
+    assert torch.isfinite(gx).all(), 'LOSS_SCALE %g overflowed the fp16 backward' % LOSS_SCALE
+    gcos = torch.nn.functional.cosine_similarity(gx.reshape(-1), x.grad.reshape(-1), dim=0).item()
+    berr = (gx - x.grad).abs().max().item() / x.grad.abs().max().item()
+    print('%s (%s): enc cos %.6f rel %.2e | input-grad cos %.6f rel %.2e | LOSS_SCALE %g finite' % (name, src, ecos, ferr, gcos, berr, LOSS_SCALE))
+    assert ecos > 0.9999 and ferr < 1e-2, (ecos, ferr)
+    assert gcos > 0.999 and berr < 5e-2, (gcos, berr)
+
+
+def test_loss_curve_stress_weights():
+    """free-running 10-step loss curve at 640x360 / 8 cuts with the stress weights: |d loss| <= 1e-3, no skipped step"""
+    model, src = stress_model('ViT-B/32', 8)
+    h, w, S, steps = 360, 640, 8, 10
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, model, S, [(tgt, -1.0)], sim='mix', transform=transforms.normalize(), rng='reference')
+    run = R.ReferenceRun(h, w, oracle_encoder(model), [(tgt, 1.0)], params=p0)
+    seed_all(9)
+    worst = 0.0
+    for i in range(steps):
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got, want = float(eng.step(table)), run.step(table)
+        worst = max(worst, abs(got - want))
+        assert abs(got - want) < 1e-3, (i, got, want)
+    assert int(eng.guard[0]) == 0, 'fp16 overflow: %d skipped steps' % int(eng.guard[0])
+    print('stress-weight loss curve (%s): max |d loss| %.2e, 0 skipped steps at LOSS_SCALE %g' % (src, worst, eng.loss_scale))
+
+
+# ------------------------------------------------------------------------------------------------ optional terms vs the oracle
+def test_sharp_expand_terms_vs_oracle(b32):
+    """--sharp (clip_fft.py:269-270) and --expand (:276-280) in the fused engine vs the oracle's restatement, three steps"""
+    h, w, S, sharp, expand = 192, 256, 4, 0.6, 0.5
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), rng='reference', sharp=sharp, expand=expand)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, sharp=sharp, expand=expand)
+    for i in range(3):
+        seed_all(10 + i)
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got, want = float(eng.step(table)), run.step(table)
+        eng.set_prev_enc()
+        assert abs(got - want) < 3e-4, (i, got, want)
+    d = (eng.params.cpu().reshape(-1) - run.params_flat()).abs()
+    assert d.mean().item() < 1e-3, d.mean().item()
+
+
+@pytest.mark.parametrize('tf', ['none', 'fast'])
+def test_enforce_term_vs_oracle(b32, tf):
+    """--enforce (clip_fft.py:271-275): a second independently drawn slice_imgs, pairwise similarity with gradient into both
+    encodings -- fused engine (forward B, backward B, recompute A, backward A) vs the oracle's autograd"""
+    h, w, S, enforce = 192, 256, 4, 0.7
+    trf = transforms.normalize() if tf == 'none' else transforms.transforms_fast
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=trf, rng='reference', enforce=enforce, use_graph=False)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, enforce=enforce)
+    seed_all(21)
+    t1, a1 = draw_crop_params(S, 224, h, w, 'uniform', 0.4, trf)
+    t2, a2 = draw_crop_params(S, 224, h, w, 'uniform', 0.4, trf)
+    got = float(eng.step(t1, a1, tables2=(t2, a2)))
+    want = run.step(t1, per_cut_of(a1), t2, per_cut_of(a2))
+    assert abs(got - want) < 3e-4, (got, want)
+    compare_grad(eng.grad, run.params.grad, 0.999, 5e-2)
+
+
+@pytest.mark.parametrize('kind', ['dwt', 'pixel'])
+def test_dwt_and_pixel_engines_vs_oracle(b32, kind):
+    """dwt_image / pixel_image parameterisers through the fused engine vs the oracle (image.py:61-80, :98-119)"""
+    from aphantasia_amd.image import dwt_image, pixel_image
+    h, w, S = 256, 320, 4
+    tgt = target512()
+    seed_all(0)
+    if kind == 'dwt':
+        params, image_f, _ = dwt_image([1, 3, h, w], 'db3', 0.3, 1.8, None)
+        eng = Engine(image_f.flat.detach().clone(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), param_kind='dwt',
+                     dwt=image_f.synth, rng='reference')
+        run = R.ReferenceRun(eng.h, eng.w, oracle_encoder(b32), [(tgt, 1.0)], params=[p.detach().cpu() for p in params], param_kind='dwt',
+                             wave='db3', dwt_sharp=0.3)
+    else:
+        params, image_f, _ = pixel_image([1, 3, h, w], sd=1.0)
+        eng = Engine(params[0].detach().clone(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), param_kind='pixel', rng='reference')
+        run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=params[0].detach().cpu(), param_kind='pixel')
+    seed_all(5)
+    table = R.draw_crop_table(S, 224, eng.h, eng.w, 'uniform', 0.4)
+    got, want = float(eng.step(table)), run.step(table)
+    assert abs(got - want) < 3e-4, (kind, got, want)
+    compare_grad(eng.grad, run.grad_flat(), 0.999, 5e-2)
+
+
+@pytest.mark.parametrize('fix', [False, True])
+def test_illustrip_rgb_step_vs_oracle(b32, fix):
+    """illustrip.py:425-440 inner step with `--gen RGB`: pixel_image(fixcontrast) + the brightness / contrast priors, vs the oracle"""
+    h, w, S = 256, 320, 4
+    tgt = target512()
+    seed_all(0)
+    p0 = torch.randn(1, 3, h, w)
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), param_kind='pixel', rng='reference',
+                 rgb_priors=True, fixcontrast=fix)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, param_kind='pixel', rgb_priors=True, fixcontrast=fix)
+    seed_all(5)
+    table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+    got, want = float(eng.step(table)), run.step(table)
+    assert abs(got - want) < 3e-4, (fix, got, want)
+    compare_grad(eng.grad, run.grad_flat(), 0.999, 5e-2)
+
+
+@pytest.mark.parametrize('gen', ['RGB', 'FFT'])
+def test_illustrip_frame_loop_vs_oracle(b32, gen):
+    """illustrip.py:381-423: per frame warp the current image (frame_transform; FFT mode: irfftn -> warp -> rfftn), re-create
+    the parameters from it and restart the optimiser -- engine (aph_frame_affine, aph_irfft2 / aph_rfft2, reset_params) vs the
+    oracle's loop (restated T.functional.affine, torch.fft, a fresh torch.optim.Adam per frame)"""
+    from aphantasia_amd import ops
+    h, w, S = 192, 256, 6
+    tgt = target512()
+    motion = (2.0, (3, -1), 1.03, 1.0)             # angle, shift, scale, shear
+    seed_all(0)
+    p0 = torch.randn(1, 3, h, w) * 0.3 if gen == 'RGB' else 0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)
+    kw = dict(sim='mix', transform=transforms.normalize(), rng='reference')
+    okw = dict(sim='mix')
+    if gen == 'RGB':
+        kw.update(param_kind='pixel', rgb_priors=True)
+        okw.update(param_kind='pixel', rgb_priors=True)
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], **kw)
+    cur = p0
+    for frame in range(3):
+        run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=cur, **okw)       # new params + new optimiser every frame (illustrip.py:390,411-418)
+        for i in range(3):
+            seed_all(100 * frame + i)
+            table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+            got, want = float(eng.step(table)), run.step(table)
+            assert abs(got - want) < 5e-4, (gen, frame, i, got, want)
+        # oracle-side re-parameterisation
+        prm = run.params.detach()
+        if gen == 'RGB':
+            cur = augment_ref.affine(prm, *motion)
+            new = transforms.frame_transform(eng.params.detach(), (h, w), *motion)
+        else:
+            img = torch.fft.irfftn(torch.view_as_complex(prm.contiguous()), s=(h, w), norm='ortho')            # illustrip.py:401-403
+            img = augment_ref.affine(img, *motion)
+            cur = torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho')).contiguous()   # :407-408
+            plan = eng.plan
+            dimg = ops.irfft2(plan, eng.params.detach())
+            dimg = transforms.frame_transform(dimg.reshape(1, 3, h, w), (h, w), *motion)
+            new = ops.rfft2(plan, dimg.reshape(3, h, w).contiguous()).reshape(1, 3, h, w // 2 + 1, 2)
+        scale = cur.abs().max().item()
+        assert (new.cpu() - cur).abs().max().item() < 2e-2 * scale, (gen, frame)
+        assert (new.cpu() - cur).abs().mean().item() < 2e-3 * scale, (gen, frame)
+        eng.reset_params(new)
+        assert eng.step_count == 0

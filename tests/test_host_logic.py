@@ -17,12 +17,15 @@ def product_lib():
 
 def test_abi_exports_match_header(product_lib):
     from aphantasia_amd import _ffi
-    hdr = open(os.path.join(ROOT, 'include', 'aphantasia_hip.h')).read()
+    # the drop-in boundary + the test / measurement hooks (separate header: not part of the boundary)
+    hdr = open(os.path.join(ROOT, 'include', 'aphantasia_hip.h')).read() + open(os.path.join(ROOT, 'include', 'aphantasia_hip_test.h')).read()
     declared = set(re.findall(r'\b(aph_[a-z0-9_]+)\s*\(', hdr))
+    boundary = set(re.findall(r'\b(aph_[a-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'aphantasia_hip.h')).read()))
+    assert not ({'aph_gemm_f16', 'aph_gemm_f16_ld', 'aph_vit_profile', 'aph_vit_profile_read'} & boundary)
     assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
     for name in declared:
         assert hasattr(product_lib.cdll, name), name          # dlsym of every header symbol
-    assert product_lib.cdll.aph_version() >= 100
+    assert product_lib.cdll.aph_version() >= 200
     # error convention: negative code + message, no compute without a GPU
     assert product_lib.cdll.aph_synth_plan_create(3, 1, 1, None) < 0
     assert 'aph_synth_plan_create' in product_lib.last_error()

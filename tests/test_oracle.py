@@ -141,3 +141,64 @@ def test_vit_restatement_vs_hf(name):
     gb, = torch.autograd.grad(b.square().sum(), x2)
     assert (a - b).abs().max().item() < 2e-5 * b.abs().max().item() + 1e-5
     assert (ga - gb).abs().max().item() < 1e-4 * gb.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a-8 (transforms_fast): torchvision is absent, so oracle/augment_ref.py stays "parity unpinned"; these are the properties
+# of the real ops (transforms.py:165-170; torchvision RandomPerspective / RandomErasing / functional.affine) that can be
+# checked without it
+# ---------------------------------------------------------------------------------------------------------------------
+def test_augment_oracle_invariants():
+    from oracle import augment_ref as A
+    n = 24
+    x = torch.rand(1, 3, n, n, generator=torch.Generator().manual_seed(3))
+    start = [[0, 0], [n - 1, 0], [n - 1, n - 1], [0, n - 1]]
+    assert np.allclose(A.perspective_coeffs(start, start), [1, 0, 0, 0, 1, 0, 0, 0], atol=1e-6)
+    assert (A.perspective(x, A.perspective_coeffs(start, start)) - x).abs().max().item() < 1e-5     # identity homography
+    assert (A.rotate(x, 0.0) - x).abs().max().item() < 1e-5                                          # 0 degrees (no shortcut upstream: grid_sample of the identity grid)
+    assert (A.rotate(x, 90.0) - torch.rot90(x, k=-1, dims=(2, 3))).abs().max().item() < 1e-5          # `affine`: clockwise
+    assert (A.rotate(x, -90.0) - torch.rot90(x, k=1, dims=(2, 3))).abs().max().item() < 1e-5
+    assert (A.rotate(A.rotate(x, 180.0), 180.0) - x).abs().max().item() < 1e-5
+    # translation homography: content moves by +t, the uncovered border is exactly the fill value 0
+    t = (3, 2)
+    y = A.perspective(x, A.perspective_coeffs(start, [[a + t[0], b + t[1]] for a, b in start]))
+    assert (y[:, :, t[1]:, t[0]:] - x[:, :, :n - t[1], :n - t[0]]).abs().max().item() < 1e-4
+    assert float(y[:, :, :t[1] - 1, :].abs().max()) == 0.0 and float(y[:, :, :, :t[0] - 1].abs().max()) == 0.0
+    # a 30-degree rotation leaves the corners (outside the rotated frame) exactly 0 and the centre value untouched in the mean
+    r = A.rotate(torch.ones(1, 3, n, n), 30.0)
+    assert float(r[0, :, 0, 0].abs().max()) == 0.0 and float(r[0, :, -1, -1].abs().max()) == 0.0
+    assert abs(float(r[0, 0, n // 2, n // 2]) - 1.0) < 1e-6
+
+
+def test_augment_draw_semantics():
+    """RandomErasing.get_params (scale (0.02, 0.33), log-uniform ratio (0.3, 3.3), value 0) and RandomPerspective.get_params
+    (distortion 0.33) bounds; the product's host draws consume the same stream as the oracle's restatement"""
+    from oracle import augment_ref as A
+    from aphantasia_amd import transforms as T
+    size = 224
+    seed_all(5)
+    n_e = n_p = 0
+    for _ in range(400):
+        rect = A.erase_get_params(size, size)
+        if rect is not None:
+            i, j, h, w = rect
+            n_e += 1
+            assert 0 <= i and i + h <= size and 0 <= j and j + w <= size and h < size and w < size
+            assert 0.02 * 0.9 <= h * w / size ** 2 <= 0.33 * 1.1 and 0.3 * 0.9 <= h / w <= 3.3 * 1.1
+        sp, ep = A.perspective_get_params(size, size, 0.33)
+        n_p += 1
+        d = int(0.33 * (size // 2))
+        assert sp == [[0, 0], [size - 1, 0], [size - 1, size - 1], [0, size - 1]]
+        for (x0, y0), (x1, y1) in zip(sp, ep):
+            assert abs(x1 - x0) <= d and abs(y1 - y0) <= d
+    assert n_e > 350
+    # same seed -> same parameters from the product's host code (aphantasia_amd/transforms.py) and the oracle's restatement
+    seed_all(77)
+    want = [A.draw_fast_params(size) for _ in range(50)]
+    seed_all(77)
+    got = [T.transforms_fast.draw(size) for _ in range(50)]
+    for a, b in zip(want, got):
+        assert a['erase'] == b['erase'] and a['angle'] == b['angle'] and (a['persp'] is None) == (b['persp'] is None)
+        if a['persp'] is not None:
+            assert np.allclose(a['persp'], b['persp'], rtol=1e-5, atol=1e-7)
+    assert sum(w['persp'] is not None for w in want) > 3 and sum(w['erase'] is not None for w in want) > 3
