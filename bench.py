@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- optimisation steps/sec of the CLIP-guided hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c1|c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 1280x720 FFT parameteriser, ViT-B/32, `--samples 200` with the
-CLI defaults (-tf fast => 190 effective cuts, clip_fft.py:167-169), sim 'mix', Adam(lr .05, b1 0).
-One step = one train(i): synth -> sampler -> ViT fwd -> loss -> ViT input-grad -> sampler adjoint ->
-rfft2 adjoint -> [all-reduce] -> Adam.  Synthetic data: seeded random ViT weights / target embedding
-(no checkpoint or network here).  N > 1 splits the cuts across ranks (strong scaling of the fixed
-200-sample step) with one RCCL all-reduce of the spectrum gradient per step.
+Default workload (BASELINE.json configs[1], "C2"): 1280x720 FFT parameteriser, ViT-B/32, `--samples 200` with the CLI
+defaults (-tf fast => 190 effective cuts, clip_fft.py:167-169), sim 'mix', Adam(lr .05, b1 0).  One step = one train(i):
+synth -> sampler -> ViT fwd -> loss -> ViT input-grad -> sampler adjoint -> rfft2 adjoint -> [all-reduce] -> Adam.
+Synthetic data: seeded random ViT weights / target embedding (no checkpoint or network here).  N > 1 splits the cuts
+across ranks (strong scaling of the fixed 200-sample step) with one RCCL all-reduce of the spectrum gradient per step.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+The ONE JSON line (rank 0) carries, besides the driver's fields:
+  * `value` = the headline (`-tf fast`, per-step frame off);
+  * `legs`  = at N = 1 the same K steps again for `-tf none` (200 cuts: the configuration whose parity with the reference is
+    pinned end to end) and for `-tf fast` with the per-step frame written as the reference does (clip_fft.py:297-306);
+  * `roofline` = the ViT GEMM family timed per launch with HIP events on the launch stream (+ `step_frac`, the whole
+    step's algorithmic FLOPs against the MFMA peak; `traffic` from the committed PMC summary of THIS build, else flagged
+    stale); `cpu_baseline` = the CPU oracle's train(i) on the host cores.
+Other configurations (`--config c1|c3|c4`) print the same line for their workload.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_IMG = {'ViT-B/32': 8817623040, 'ViT-B/16': 35126906880}     # SURVEY.md section 8d (fwd FLOPs / image)
+PEAK_TF, HBM_ACHIEVABLE_GBS = 2500.0, 6300.0                    # MI355X_MICROARCH.md: dense f16 MFMA; achievable HBM3E
+
+CONFIGS = {     # SURVEY.md section 8 config shorthand
+    'c1': dict(size='224-224', samples=1, model='ViT-B/32', transform='none', macro=0.0, note='BASELINE configs[0] (reference plumbing case; S = 1, -tf none, --macro 0)'),
+    'c2': dict(size='1280-720', samples=200, model='ViT-B/32', transform='fast', macro=0.4, note='BASELINE configs[1] (the headline)'),
+    'c3': dict(size='1280-720', samples=200, model='ViT-B/32', transform='fast', macro=0.4, dualmod=2, note='BASELINE configs[2]: --dualmod 2, ViT-B/32 <-> ViT-B/16 on one Adam state'),
+    'c4': dict(size='3840-2160', samples=400, model='ViT-B/16', transform='fast', macro=0.4, dwt='db3', note='BASELINE configs[3]: --dwt -w db3, ViT-B/16'),
+}
 
 
 def parse():
@@ -34,14 +50,34 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=50)
     p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--size', default='1280-720')
-    p.add_argument('--samples', type=int, default=200)
-    p.add_argument('--model', default='ViT-B/32')
-    p.add_argument('--transform', default='fast', choices=['fast', 'none'])
+    p.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    p.add_argument('--size', default=None)
+    p.add_argument('--samples', type=int, default=None)
+    p.add_argument('--model', default=None)
+    p.add_argument('--transform', default=None, choices=['fast', 'none'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-legs', action='store_true', help='skip the -tf none and with-save legs (N = 1 only has them)')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    return p.parse_args()
+    a = p.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k in ('size', 'samples', 'model', 'transform'):
+        if getattr(a, k) is not None:
+            cfg[k] = getattr(a, k)
+    a.cfg = cfg
+    return a
+
+
+def derate(samples, model, transform, dualmod):
+    """clip_fft.py:125-127,134,167-169"""
+    s = samples
+    if model == 'ViT-B/16':
+        s = int(s * 0.25)
+    if dualmod is not None:
+        s = int(s * 0.23)
+    if transform == 'fast':
+        s = int(s * 0.95)
+    return s
 
 
 def cpu_baseline(w, h, model_name, samples, seed=0):
@@ -55,18 +91,36 @@ def cpu_baseline(w, h, model_name, samples, seed=0):
     target = torch.randn(1, cfg['output_dim'], generator=torch.Generator().manual_seed(2))
     torch.manual_seed(seed)
     run = R.ReferenceRun(h, w, lambda x: clip_vit_ref.encode_image(wts, x, cfg), [(target, 1.0)])
-    run.step(R.draw_crop_table(4, 224, h, w, 'uniform', 0.4))
+    run.step(R.draw_crop_table(min(4, samples), 224, h, w, 'uniform', 0.4))
     table = R.draw_crop_table(samples, 224, h, w, 'uniform', 0.4)
     t0 = time.perf_counter()
     run.step(table)
     dt = time.perf_counter() - t0
     return dict(value=1.0 / dt, unit='steps/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 full train(i) at %dx%d, %d cuts, %s, fp32 torch-CPU oracle (-tf none), after a 4-cut warm-up step'
-                       % (w, h, samples, model_name), seconds=dt)
+                sample='1 full train(i) at %dx%d, %d cuts, %s, fp32 torch-CPU oracle (-tf none), after a %d-cut warm-up step'
+                       % (w, h, samples, model_name, min(4, samples)), seconds=dt)
+
+
+def lib_sha():
+    from aphantasia_amd import _ffi
+    with open(_ffi.LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_traffic(tag_glob):
+    """HBM-side bytes per GEMM launch from the newest committed PMC summary (tools/pmc_traffic.py); stale unless it was
+    taken on the very library that is being timed"""
+    pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', tag_glob)), key=os.path.getmtime)
+    if not pm:
+        return None, None, None
+    with open(pm[-1]) as f:
+        j = json.load(f)
+    return j.get('traffic_bytes_per_launch'), os.path.relpath(pm[-1], ROOT), j.get('lib_sha256') != lib_sha()
 
 
 def main():
     a = parse()
+    cfg = a.cfg
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -90,23 +144,36 @@ def main():
     from aphantasia_amd import clip as aclip, transforms
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.clip import LOSS_SCALE
-    w, h = [int(s) for s in a.size.split('-')]
+    w, h = [int(s) for s in cfg['size'].split('-')]
+    dualmod = cfg.get('dualmod')
+    S = derate(cfg['samples'], cfg['model'], cfg['transform'], dualmod)
+    S_none = derate(cfg['samples'], cfg['model'], 'none', dualmod)
+    if S < 1:
+        raise SystemExit('no effective cuts')
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model, _ = aclip.load(a.model, weights=None, seed=1, max_batch=8)
-    S = a.samples
-    if a.model == 'ViT-B/16':
-        S = int(S * 0.25)                                   # clip_fft.py:125-127
-    trf = transforms.normalize()
-    if a.transform == 'fast':
-        S = int(S * 0.95)                                   # clip_fft.py:167-169
-        trf = transforms.transforms_fast
-    torch.manual_seed(0)
-    np.random.seed(0)
-    params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
+        model, _ = aclip.load(cfg['model'], weights=None, seed=1, max_batch=8)
+        model2 = aclip.load('ViT-B/16', weights=None, seed=1, max_batch=8)[0] if dualmod is not None else None
+    sim = 'cossim' if dualmod is not None else 'mix'                  # clip_fft.py:88
     target = torch.randn(1, model.visual.output_dim, generator=torch.Generator().manual_seed(2))
-    eng = Engine(params, h, w, model, S, [(target, -1.0)], sim='mix', transform=trf, macro=0.4,
-                 rank=rank, world=world, process_group=pg, use_graph=not a.no_graph)
+    target2 = torch.randn(1, model.visual.output_dim, generator=torch.Generator().manual_seed(3))
+
+    def make(transform_name, S_eff):
+        """(engines [main, dual or None], synth) on freshly initialised parameters"""
+        trf = transforms.transforms_fast if transform_name == 'fast' else transforms.normalize()
+        torch.manual_seed(0)
+        np.random.seed(0)
+        kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, use_graph=not a.no_graph)
+        if cfg.get('dwt'):
+            from aphantasia_amd.image import dwt_image
+            params, image_f, _ = dwt_image([1, 3, h, w], cfg['dwt'], 0.3, 1.8, None)
+            leaf = image_f.flat
+            kw.update(param_kind='dwt', dwt=image_f.synth)
+        else:
+            leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
+        e1 = Engine(leaf, h, w, model, S_eff, [(target, -1.0)], **kw)
+        e2 = Engine(leaf, h, w, model2, S_eff, [(target2, -1.0)], state=e1.state(), **kw) if dualmod is not None else None
+        return e1, e2
 
     def sync():
         if world > 1:
@@ -114,69 +181,145 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        eng.step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        eng.step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    def timed(e1, e2, steps, warmup, writer=None, tmpdir=None):
+        """exactly `steps` steps between barrier + synchronize pairs; MAX over ranks"""
+        def one(i):
+            e = e2 if (e2 is not None and i >= dualmod and i % dualmod == 0) else e1          # list(range(steps))[dm::dm], clip_fft.py:135
+            e.step()
+            if writer is not None:                                                             # clip_fft.py:297-306 (opt_step = 1)
+                img = e.synthesize(1.1)
+                writer.put(img.reshape(3, e.h, e.w), os.path.join(tmpdir, '%04d.jpg' % i), 1.0)
+        for i in range(warmup):
+            one(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        if writer is not None:
+            writer.drain()                        # every frame of the timed region is on disk before the clock stops
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    eng, eng_b = make(cfg['transform'], S)
+    dt = timed(eng, eng_b, a.steps, a.warmup)
     loss = eng.global_loss()
+    flop_step = 2 * S * F_IMG[cfg['model']] / 1e12
+    if dualmod is not None:     # the schedule's mix of B/32 and B/16 steps over the timed region
+        n16 = len([i for i in range(a.steps) if i >= dualmod and i % dualmod == 0])
+        flop_step = 2 * S * (F_IMG['ViT-B/32'] * (a.steps - n16) + F_IMG['ViT-B/16'] * n16) / a.steps / 1e12
 
     roof = None
     if not a.no_roofline:
         # same steps again with HIP events around every GEMM launch of the ViT (dominant kernel family)
         lib = eng.lib
-        h_ = eng.visual.handle
-        eng.use_graph = False             # eager launches so that every GEMM gets its event pair
-        lib.call('aph_vit_profile', h_.handle, 1)
-        for _ in range(min(a.steps, 10)):
-            eng.step()
-        torch.cuda.synchronize()
         import ctypes
-        ms, n = ctypes.c_double(), ctypes.c_longlong()
-        flops = ctypes.c_double()
-        lib.call('aph_vit_profile_read', h_.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(flops))
-        lib.call('aph_vit_profile', h_.handle, 0)
-        if n.value > 0:
-            achieved = flops.value / (ms.value * 1e-3) / 1e12
-            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (a PMC pass cannot run inside this process);
-            # the committed summary of the latest pass is quoted when the workload is the one it was taken on
-            traffic, tsrc = None, None
-            import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_*.json')))
-            if pm and (w, h, a.model, a.samples, a.transform) == (1280, 720, 'ViT-B/32', 200, 'fast') and world == 1:
-                with open(pm[-1]) as f:
-                    traffic = json.load(f)['traffic_bytes_per_launch']
-                tsrc = os.path.relpath(pm[-1], ROOT)
-            roof = dict(bound='mfma', kernel='aph::gemm_f16_kernel<*> / aph::gemm8_f16_kernel<*>', achieved=achieved, peak=2500.0,
-                        unit='TFLOP/s', frac=achieved / 2500.0, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
-                        traffic_source=tsrc, launches_per_step=n.value // min(a.steps, 10),
-                        avg_launch_us=ms.value * 1e3 / n.value, flops_per_launch=flops.value / n.value,
+        vits = [e.visual.handle for e in (eng, eng_b) if e is not None]
+        for e in (eng, eng_b):
+            if e is not None:
+                e.use_graph = False       # eager launches so that every GEMM gets its event pair
+        for v in vits:
+            lib.call('aph_vit_profile', v.handle, 1)
+        nprof = min(a.steps, 10)
+        for i in range(nprof):
+            (eng_b if (eng_b is not None and i >= dualmod and i % dualmod == 0) else eng).step()
+        torch.cuda.synchronize()
+        ms_t, n_t, fl_t = 0.0, 0, 0.0
+        for v in vits:
+            ms, n, flops = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+            lib.call('aph_vit_profile_read', v.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(flops))
+            lib.call('aph_vit_profile', v.handle, 0)
+            ms_t, n_t, fl_t = ms_t + ms.value, n_t + n.value, fl_t + flops.value
+        if n_t > 0:
+            achieved = fl_t / (ms_t * 1e-3) / 1e12
+            traffic, tsrc, stale = (None, None, None)
+            if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1:
+                traffic, tsrc, stale = pmc_traffic('r*_pmc_hbm_traffic*.json')
+            roof = dict(bound='mfma', kernel='aph::gemm_f16_kernel<*> / aph::gemm8_f16_kernel<*>', achieved=achieved, peak=PEAK_TF,
+                        unit='TFLOP/s', frac=achieved / PEAK_TF, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
+                        traffic_source=tsrc, traffic_stale=stale, launches_per_step=n_t // nprof,
+                        avg_launch_us=ms_t * 1e3 / n_t, flops_per_launch=fl_t / n_t, gemm_ms_per_step=ms_t / nprof,
+                        step_frac=flop_step * (a.steps / dt) / PEAK_TF,
+                        step_frac_note='algorithmic_tflop_per_step x steps/s / peak (whole step, every kernel and gap included)',
                         peak_measured_random_operands=1800.0)
+        if cfg.get('dwt'):
+            # the HBM-bound part of C4: inverse DWT forward + adjoint, timed with events on the (current) launch stream
+            syn = eng.dwt
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            graw = torch.randn_like(eng.raw)
+            reps = 20
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                syn.forward(eng.params)
+            e1.record()
+            for _ in range(reps):
+                syn.backward(graw, eng.grad)
+            e2.record()
+            torch.cuda.synchronize()
+            elems = 0
+            for (hh, ww), (ho, wo) in zip(syn.sizes, syn.out_sizes):
+                elems += 3 * (4 * hh * ww + ho * wo)              # read ll + 3 detail bands, write the level's output
+            by = 4.0 * elems
+            tf, tb = e0.elapsed_time(e1) / reps * 1e-3, e1.elapsed_time(e2) / reps * 1e-3
+            roof_dwt = dict(bound='hbm', kernel='aph::idwt_level_kernel / idwt_level_adjoint_kernel (all levels)', unit='GB/s',
+                            peak=HBM_ACHIEVABLE_GBS, algorithmic_bytes_per_pass=by, fwd_us=tf * 1e6, bwd_us=tb * 1e6,
+                            achieved=by / tf / 1e9, frac=by / tf / 1e9 / HBM_ACHIEVABLE_GBS,
+                            achieved_adjoint=by / tb / 1e9, frac_adjoint=by / tb / 1e9 / HBM_ACHIEVABLE_GBS)
+            roof = dict(roof or {}, irdwt=roof_dwt)
+
+    legs = None
+    if world == 1 and not a.no_legs and a.config in ('c2', 'c3', 'c4') and cfg['transform'] == 'fast':
+        legs = {}
+        e_n, e_nb = make('none', S_none)
+        dtn = timed(e_n, e_nb, a.steps, a.warmup)
+        legs['tf_none'] = dict(value=a.steps / dtn, unit='steps/s', ms_per_step=1e3 * dtn / a.steps, samples_effective=S_none,
+                               note='-tf none: the configuration whose parity with the reference is pinned end to end (tests/test_gpu_parity_configs.py)')
+        del e_n, e_nb
+        import shutil
+        import tempfile
+        import clip_fft
+        tmpdir = tempfile.mkdtemp(prefix='aph_bench_frames_')
+        try:
+            e_s, e_sb = make(cfg['transform'], S)
+            writer = clip_fft.FrameWriter(e_s.h, e_s.w)
+            dts = timed(e_s, e_sb, a.steps, a.warmup, writer, tmpdir)
+            writer.close()
+            nfr = len([f for f in os.listdir(tmpdir) if f.endswith('.jpg')])
+            legs['with_save'] = dict(value=a.steps / dts, unit='steps/s', ms_per_step=1e3 * dts / a.steps, frames_written=nfr,
+                                     note='per-step frame on (clip_fft.py:297-306, opt_step 1): image_f(contrast 1.1) -> uint8 on the device '
+                                          '-> pinned ring -> %d JPEG encoder threads; all frames on disk before the clock stops' % clip_fft.FrameWriter.THREADS)
+        finally:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(w, h, a.model, S)
+        if cfg.get('dwt') or dualmod is not None:
+            cpu = None          # the oracle leg is defined for the FFT single-model step; C3 / C4 lines report the GPU side only
+        else:
+            cpu = cpu_baseline(w, h, cfg['model'], S)
 
     if rank == 0:
         steps_per_s = a.steps / dt
+        kind = 'DWT %s' % cfg['dwt'] if cfg.get('dwt') else 'FFT'
         out = {
-            'metric': 'optimization steps/sec @%dx%d %s samples=%d' % (w, h, a.model, a.samples),
+            'metric': 'optimization steps/sec @%dx%d %s samples=%d' % (w, h, cfg['model'], cfg['samples']),
             'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f16 (MFMA operands, fp32 accumulate; fp32 synth/sampler/loss/Adam)', 'data': 'synthetic',
-            'config': {'workload': '%dx%d FFT parameteriser, %s, --samples %d -> %d effective cuts, -tf %s, sim mix, '
-                                   'Adam(lr .05, b1 0), per-step image save off' % (w, h, a.model, a.samples, S, a.transform),
-                       'samples_effective': S, 'parallelism': 'samples split over %d rank(s), 1 all-reduce/step' % world,
-                       'loss_scale': LOSS_SCALE, 'final_loss': loss,
-                       'algorithmic_tflop_per_step': 2 * S * F_IMG[a.model] / 1e12},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'config': {'workload': '%s: %dx%d %s parameteriser, %s%s, --samples %d -> %d effective cuts, -tf %s, sim %s, '
+                                   'Adam(lr .05, b1 0), per-step image save off' % (a.config.upper(), w, h, kind, cfg['model'],
+                                                                                    ' + ViT-B/16 every %d steps (--dualmod)' % dualmod if dualmod else '',
+                                                                                    cfg['samples'], S, cfg['transform'], sim),
+                       'note': cfg['note'], 'samples_effective': S, 'parallelism': 'samples split over %d rank(s), 1 all-reduce/step' % world,
+                       'loss_scale': LOSS_SCALE, 'final_loss': loss, 'algorithmic_tflop_per_step': flop_step,
+                       'lib_sha256': lib_sha()[:16]},
+            'legs': legs, 'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -144,10 +144,14 @@ class FrameWriter:
         while True:
             item = self.q.get()
             if item is None:
+                self.q.task_done()
                 return
             buf, ev, fname = item
-            ev.synchronize()
-            Image.fromarray(buf.numpy()).save(fname, quality=95)
+            try:
+                ev.synchronize()
+                Image.fromarray(buf.numpy()).save(fname, quality=95)
+            finally:
+                self.q.task_done()
 
     def put(self, img, fname, gamma=1.0):
         """img: device float [3,H,W] in [0,1]; same arithmetic as utils.checkout: clip(img*255, 0, 255).astype(uint8)"""
@@ -158,6 +162,10 @@ class FrameWriter:
         buf.copy_((img * 255).clamp_(0, 255).to(torch.uint8).permute(1, 2, 0), non_blocking=True)
         ev = torch.cuda.Event(); ev.record()
         self.q.put((buf, ev, fname))
+
+    def drain(self):
+        """block until every frame handed to put() is on disk"""
+        self.q.join()
 
     def close(self):
         for _ in self.ts: self.q.put(None)
