@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libaphantasia_hip.so')
-SOURCES = ['api.hip', 'synth.hip', 'dwt.hip', 'sampler.hip', 'loss_adam.hip', 'vit.hip']
+SOURCES = ['api.hip', 'synth.hip', 'dwt.hip', 'sampler.hip', 'loss_adam.hip', 'vit.hip', 'comm.hip']
 
 
 def _stale():
@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
         if verbose and out.strip():
             print(out.decode(errors='replace'))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

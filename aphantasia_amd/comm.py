@@ -1,0 +1,86 @@
+"""The multi-GPU collective: one all-reduce of the parameter gradient per step, RCCL called
+directly through the C ABI (aph_comm_* in csrc/comm.hip).  One process per GPU; the 128-byte RCCL unique id is the only
+thing that travels out of band -- through an already-initialised torch.distributed group when there is one (bench.py under
+torchrun: a one-off control-plane broadcast), else through a rendezvous file (clip_fft.py --ranks).
+"""
+import ctypes
+import os
+import time
+
+import torch
+
+from . import _ffi
+
+
+class Comm:
+    def __init__(self, rank, world, uid, lib=None):
+        self.lib = lib if lib is not None else _ffi.lib()
+        self.rank, self.world = int(rank), int(world)
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(uid))
+        self.lib.call('aph_comm_init', self.rank, self.world, ctypes.cast(buf, ctypes.c_void_p), ctypes.byref(h))
+        self.handle = h
+
+    def all_reduce_(self, t, stream=None):
+        """in-place sum over the ranks of a contiguous f32 CUDA tensor, asynchronous on `stream` (default: torch's current)"""
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError('all_reduce_ expects a contiguous f32 CUDA tensor')
+        st = ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if stream is None else stream
+        self.lib.call('aph_allreduce_f32', self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), st)
+        return t
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.cdll.aph_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def new_unique_id(lib=None):
+    L = lib if lib is not None else _ffi.lib()
+    buf = (ctypes.c_char * 128)()
+    L.call('aph_comm_unique_id', ctypes.cast(buf, ctypes.c_void_p))
+    return bytes(buf)
+
+
+def _file_exchange(rank, world, uid, key, timeout=120.0):
+    """rank 0 publishes the id in a rendezvous file, the others wait for it (all ranks share one node's /tmp)"""
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'aph_rccl_uid_%s' % key)
+    if rank == 0:
+        tmp = path + '.%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if os.path.isfile(path) and os.path.getsize(path) == 128 and os.path.getmtime(path) >= _START - 2.0:
+            with open(path, 'rb') as f:
+                return f.read()
+        time.sleep(0.02)
+    raise RuntimeError('no RCCL unique id at %s after %.0f s (is rank 0 running with the same rendezvous key?)' % (path, timeout))
+
+
+_START = time.time()
+
+
+def create(rank, world, device=None, lib=None, key=None):
+    """Comm over `world` ranks of this node.  Must be called by every rank with its GPU current."""
+    if device is not None:
+        torch.cuda.set_device(device)
+    uid = new_unique_id(lib) if rank == 0 else None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)                    # one-off control-plane exchange of 128 bytes
+        uid = bytes(t.cpu().tolist())
+    else:
+        key = key or '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', os.environ.get('APH_RUN_ID', 'x')))
+        uid = _file_exchange(rank, world, uid, key)
+    return Comm(rank, world, uid, lib)

@@ -93,6 +93,37 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_f16(half8 a, half8 b, f32x4 c) {
 #endif
 }
 
+// v_mfma_f32_32x32x16_f16:  D[32x32] += A[32x16] * B[16x32]   (half the instructions of 16x16x32 for the same flops;
+// the same LDS bytes per flop at equal wave tile, a higher sustained rate -- MI355X_MICROARCH.md, matrix cores)
+//   A operand: lane l holds A[i = l & 31][k = (l >> 5) * 8 + j], j = 0..7
+//   B operand: lane l holds B[k = (l >> 5) * 8 + j][n = l & 31]
+//   C/D:       lane l, reg r holds D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][n = l & 31]
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(half8 a, half8 b, f32x16 c) {
+#ifdef APH_EMU
+  struct Slot { half8 a, b; };
+  const int lane = emu::lane_id();
+  Slot s{a, b};
+  memcpy(emu::wave_slot(lane), &s, sizeof(s));
+  emu::wave_barrier();
+  const int n = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      Slot sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 32 * (k / 8)), sizeof(Slot));
+      memcpy(&sb, emu::wave_slot(n + 32 * (k / 8)), sizeof(Slot));
+      acc += (float)sa.a[k % 8] * (float)sb.b[k % 8];
+    }
+    c[r] = acc;
+  }
+  emu::wave_barrier();
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // global_load_lds_dwordx4: each lane copies 16 bytes from its own global address straight into LDS at
 // (wave-uniform base) + lane * 16 -- asynchronous, tracked by vmcnt, no VGPR staging.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

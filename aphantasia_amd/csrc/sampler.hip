@@ -35,15 +35,19 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
   w[3] = ((A * (x2 + 1.0f) - 5.0f * A) * (x2 + 1.0f) + 8.0f * A) * (x2 + 1.0f) - 4.0f * A;
 }
 
+// four consecutive floats at 4-byte alignment: the compiler emits one global_load_dwordx4 (gfx950 handles the misalignment)
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };
+
 __device__ __forceinline__ int wrap(int v, int n) {
   v %= n;
   return v < 0 ? v + n : v;
 }
 
-// patch-major element offset of pixel (c,i,j) of cut s
+// patch-major element offset of pixel (c,i,j) of cut s.  The patch side p is a power of two (checked on the host):
+// shifts and masks instead of integer divisions in the per-pixel index arithmetic.
 __device__ __forceinline__ size_t patch_index(int s, int c, int i, int j, int size, int p) {
-  const int g = size / p;
-  return ((size_t)s * g * g + (size_t)(i / p) * g + (j / p)) * (size_t)(3 * p * p) + (size_t)c * p * p + (i % p) * p + (j % p);
+  const int lp = __ffs(p) - 1, g = size >> lp;
+  return ((size_t)s * g * g + (size_t)(i >> lp) * g + (j >> lp)) * (size_t)(3 << (2 * lp)) + ((size_t)c << (2 * lp)) + ((i & (p - 1)) << lp) + (j & (p - 1));
 }
 
 template <int OUT>
@@ -107,16 +111,18 @@ __device__ __forceinline__ void emit3(void* out, int s, int i, int j, int size, 
 // ---------------------------------------------------------------------------------
 // crop + bicubic resize  (utils.py:248-249)
 // ---------------------------------------------------------------------------------
-template <int OUT>
-__global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g) {
-  const int s = blockIdx.y;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= g.size * g.size) return;
-  const int i = pix / g.size, j = pix - i * g.size;
-  const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+struct CutBox { int cs, ox, oy; float scale; };
+__device__ __forceinline__ CutBox load_cut(const int* __restrict__ table, int s, int size) {
+  CutBox b;
+  b.cs = table[3 * s]; b.ox = table[3 * s + 1]; b.oy = table[3 * s + 2];
   // area_pixel_compute_scale(align_corners=True): (in-1)/(out-1), source index = scale*dst, all fp32
-  const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
-  const float sy = scale * (float)i, sx = scale * (float)j;
+  b.scale = size > 1 ? (float)(b.cs - 1) / (float)(size - 1) : 0.f;
+  return b;
+}
+
+// bicubic value (all three channels) of resized-cut pixel (i, j): utils.py:248-249
+__device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Geom& g, const CutBox& b, int i, int j, float v[3]) {
+  const float sy = b.scale * (float)i, sx = b.scale * (float)j;
   const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
   float wy[4], wx[4];
   cubic_w(sy - (float)y0, wy);
@@ -124,12 +130,14 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __r
   int ry[4], rx[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    int yy = y0 - 1 + k; yy = yy < 0 ? 0 : (yy > cs - 1 ? cs - 1 : yy);   // clamp inside the cut
-    int xx = x0 - 1 + k; xx = xx < 0 ? 0 : (xx > cs - 1 ? cs - 1 : xx);
-    ry[k] = wrap(oy + yy - g.py0, g.H);                                     // tile_pad wrap (utils.py:165-167)
-    rx[k] = wrap(ox + xx - g.px0, g.W);
+    int yy = y0 - 1 + k; yy = yy < 0 ? 0 : (yy > b.cs - 1 ? b.cs - 1 : yy);   // clamp inside the cut
+    int xx = x0 - 1 + k; xx = xx < 0 ? 0 : (xx > b.cs - 1 ? b.cs - 1 : xx);
+    ry[k] = wrap(b.oy + yy - g.py0, g.H);                                       // tile_pad wrap (utils.py:165-167)
+    rx[k] = wrap(b.ox + xx - g.px0, g.W);
   }
-  float v[3];
+  // the four column taps are consecutive source pixels unless the clamp at the cut's edge or the wrap at the image's
+  // edge intervenes: one 16-byte load per tap row (4-byte aligned) instead of four scalar gathers
+  const bool run4 = rx[3] == rx[0] + 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* pl = rgb + (size_t)c * g.H * g.W;
@@ -137,11 +145,32 @@ __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __r
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const float* row = pl + (size_t)ry[a] * g.W;
-      const float r = row[rx[0]] * wx[0] + row[rx[1]] * wx[1] + row[rx[2]] * wx[2] + row[rx[3]] * wx[3];
+      float r;
+      if (run4) {
+        const F4u t = *reinterpret_cast<const F4u*>(row + rx[0]);
+        r = t.v[0] * wx[0] + t.v[1] * wx[1] + t.v[2] * wx[2] + t.v[3] * wx[3];
+      } else {
+        r = row[rx[0]] * wx[0] + row[rx[1]] * wx[1] + row[rx[2]] * wx[2] + row[rx[3]] * wx[3];
+      }
       acc += r * wy[a];
     }
     v[c] = acc;
   }
+}
+
+// `only_persp` (with an augment table): just the cuts that drew a perspective -- the others are produced by
+// crop_warp_fused_kernel without the scratch round trip
+template <int OUT>
+__global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g,
+                                   const float* __restrict__ only_persp) {
+  const int s = blockIdx.y;
+  if (only_persp && only_persp[(size_t)s * APH_AUG_STRIDE + 8] == 0.f) return;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= g.size * g.size) return;
+  const int i = pix / g.size, j = pix - i * g.size;
+  const CutBox b = load_cut(table, s, g.size);
+  float v[3];
+  bicubic3(rgb, g, b, i, j, v);
   emit3<OUT>(out, s, i, j, g.size, g.patch, v[0], v[1], v[2]);
 }
 
@@ -161,12 +190,12 @@ struct AdjEntry {
 // separable offset parts of gradient element (i, j) in layout OUT (channel/cut base added by the caller)
 template <int OUT>
 __device__ __forceinline__ int grad_rowpart(int i, int size, int p) {
-  if (is_patch<OUT>::v) return (i / p) * (size / p) * (3 * p * p) + (i % p) * p;
+  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (i >> lp) * (size >> lp) * (3 << (2 * lp)) + ((i & (p - 1)) << lp); }
   return i * size;
 }
 template <int OUT>
 __device__ __forceinline__ int grad_colpart(int j, int /*size*/, int p) {
-  if (is_patch<OUT>::v) return (j / p) * (3 * p * p) + (j % p);
+  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (j >> lp) * (3 << (2 * lp)) + (j & (p - 1)); }
   return j;
 }
 
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
   __shared__ int vlist[MAXV];
   __shared__ int vcount;
   __shared__ AdjEntry ent[NB][32];
-  __shared__ int vinfo[NB][2];     // cut index, generic-path flag
+  __shared__ int vinfo[NB][3];     // cut index, generic-path flag, longest run of outputs per source position
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
   const bool live = x < g.W && y < g.H;
@@ -273,7 +302,11 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
           const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
           const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
           const bool generic = !(scale >= 1.0f);
-          if (idx == 0) { vinfo[vb][0] = v; vinfo[vb][1] = generic ? 1 : 0; }
+          // a source position lies inside the 4-tap windows of at most floor(4 / scale) + 1 outputs per axis (<= 4 entries):
+          // wave-uniform loop bounds instead of 4 x 4 mostly-zero products for the (common) strongly down-sampling cuts
+          int run = (int)floorf(4.0f / (scale > 1.0f ? scale : 1.0f)) + 1;
+          run = run > 4 ? 4 : run;
+          if (idx == 0) { vinfo[vb][0] = v; vinfo[vb][1] = generic ? 1 : 0; vinfo[vb][2] = run; }
           if (!generic) {
             const bool isrow = idx < 16;
             const int q = isrow ? wrap(ty0 + idx + g.py0, g.H) + ay * g.H - oy : wrap(tx0 + (idx - 16) + g.px0, g.W) + ax * g.W - ox;
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
             const int absq = q + (isrow ? oy : ox);
             if (q >= 0 && q < cs && q < maxcs && absq < lim) e = tab[((size_t)s * 2 + (isrow ? 0 : 1)) * maxcs + q];
           }
-        } else if (idx == 0) { vinfo[vb][0] = -1; vinfo[vb][1] = 0; }
+        } else if (idx == 0) { vinfo[vb][0] = -1; vinfo[vb][1] = 0; vinfo[vb][2] = 0; }
         ent[vb][idx] = e;
       }
       __syncthreads();
@@ -317,11 +350,14 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
         const AdjEntry re = ent[vb][ty], ce = ent[vb][16 + tx];
         if (re.w[0] == 0.f && re.w[1] == 0.f) continue;     // (a run starts with its first non-zero weight)
         const size_t gb = (size_t)s * ccut;
+        const int run = vinfo[vb][2];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
+          if (a >= run) break;
           if (re.w[a] == 0.f) continue;
 #pragma unroll
           for (int bq = 0; bq < 4; ++bq) {
+            if (bq >= run) break;
             if (ce.w[bq] == 0.f) continue;
             const float w = re.w[a] * ce.w[bq];
             const int o = re.off[a] + ce.off[bq];
@@ -425,9 +461,10 @@ __global__ void persp_kernel(const float* __restrict__ A, const float* __restric
 // stage 2: RandomErasing (read-side) + rotation + normalise + emit
 template <int OUT>
 __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __restrict__ Bi, const float* __restrict__ aug,
-                                   void* __restrict__ out, int n, int patch) {
+                                   void* __restrict__ out, int n, int patch, int only_persp) {
   const int s = blockIdx.y;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
+  if (only_persp && a[8] == 0.f) return;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= n * n) return;
   const int i = pix / n, j = pix - i * n;
@@ -441,6 +478,127 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
     float v[3];
     for (int c = 0; c < 3; ++c) v[c] = in_rect(a, i, j) ? 0.f : src[((size_t)s * 3 + c) * n * n + pix];
     emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
+  }
+}
+
+// Cuts WITHOUT a perspective (80 % of them under transforms_fast): bicubic resize -> RandomErasing -> rotation -> normalise
+// -> emit in ONE kernel.  The stages stay sequential (transforms.py:165-170: every rotated pixel is a bilinear blend of four
+// pixels of the resized, erased cut) -- the intermediate cut simply lives in LDS instead of HBM: a workgroup owns a 32x32
+// output tile, builds the part of the resized cut its rotated footprint touches (<= 32 sqrt(2) + taps per side) and samples
+// it.  Replaces a 114 MB f32 scratch write + gather read per step at the headline size.
+constexpr int kFT = 32;        // output tile side
+constexpr int kFMAX = 52;      // footprint side bound: 32 * sqrt(2) = 45.3, + 2 taps, + rounding margin
+
+template <int OUT>
+__global__ __launch_bounds__(256) void crop_warp_fused_kernel(const float* __restrict__ rgb, const int* __restrict__ table,
+                                                              const float* __restrict__ aug, void* __restrict__ out, Geom g) {
+  __shared__ float fp[3][kFMAX][kFMAX + 1];
+  __shared__ __attribute__((aligned(16))) half_t stg[3 * kFT * kFT];
+  const int s = blockIdx.y;
+  const float* a = aug + (size_t)s * APH_AUG_STRIDE;
+  if (a[8] != 0.f) return;                      // perspective cuts: scratch path
+  const int n = g.size, tiles = (n + kFT - 1) / kFT;
+  const int tby = blockIdx.x / tiles, tbx = blockIdx.x - tby * tiles;
+  const int ti0 = tby * kFT, tj0 = tbx * kFT;
+  const int ti1 = (ti0 + kFT < n ? ti0 + kFT : n) - 1, tj1 = (tj0 + kFT < n ? tj0 + kFT : n) - 1;
+  const bool rot = a[15] != 0.f;
+  const float rc = a[13], rs = a[14];
+  const CutBox b = load_cut(table, s, n);
+  int x0 = tj0, x1 = tj1, y0 = ti0, y1 = ti1;
+  if (rot) {
+    // the map is affine, floor is monotone: the extreme taps of the tile are those of its corners (+-1 for fp rounding)
+    int xa = 1 << 30, xb = -(1 << 30), ya = 1 << 30, yb = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Tap t = rot_tap(rc, rs, (k & 2) ? ti1 : ti0, (k & 1) ? tj1 : tj0, n);
+      xa = t.x0 < xa ? t.x0 : xa; xb = t.x0 > xb ? t.x0 : xb;
+      ya = t.y0 < ya ? t.y0 : ya; yb = t.y0 > yb ? t.y0 : yb;
+    }
+    x0 = xa - 1; x1 = xb + 2; y0 = ya - 1; y1 = yb + 2;
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > n - 1 ? n - 1 : x1; y1 = y1 > n - 1 ? n - 1 : y1;
+  }
+  const int FW = x1 - x0 + 1, FH = y1 - y0 + 1;
+  const bool staged = FW >= 1 && FH >= 1 && FW <= kFMAX && FH <= kFMAX;      // always, for a rotation; else: taps straight from the image
+  if (staged) {
+    const float c = 0.5f * (float)(n - 1);
+    for (int idx = threadIdx.x; idx < FH * FW; idx += blockDim.x) {
+      const int fy = idx / FW, fx = idx - fy * FW, y = y0 + fy, x = x0 + fx;
+      if (rot) {
+        // only pixels within two pixels of the tile's pre-image can be tapped: skip the corners of the bounding box
+        const float ux = (float)x - c, uy = (float)y - c;
+        const float qx = rc * ux - rs * uy + c, qy = rs * ux + rc * uy + c;
+        if (qx < (float)tj0 - 2.5f || qx > (float)tj1 + 2.5f || qy < (float)ti0 - 2.5f || qy > (float)ti1 + 2.5f) continue;
+      }
+      float v[3] = {0.f, 0.f, 0.f};
+      if (!in_rect(a, y, x)) bicubic3(rgb, g, b, y, x, v);                    // RandomErasing: value 0 inside the rectangle
+      fp[0][fy][fx] = v[0]; fp[1][fy][fx] = v[1]; fp[2][fy][fx] = v[2];
+    }
+  }
+  __syncthreads();
+  // patch-major f16 output of a full tile: stage in output order, then 16-byte stores (whole lines instead of 2-byte scatters)
+  const int p = g.patch;
+  const bool pack = OUT == APH_OUT_PATCH_F16 && p >= 4 && p <= kFT && ti1 - ti0 == kFT - 1 && tj1 - tj0 == kFT - 1 && (ti0 % p) == 0;
+  const int lp = pack ? __ffs(p) - 1 : 0;
+  for (int pix = threadIdx.x; pix < kFT * kFT; pix += blockDim.x) {
+    const int li = pix / kFT, lj = pix - li * kFT, i = ti0 + li, j = tj0 + lj;
+    if (i > ti1 || j > tj1) continue;
+    float v[3];
+    if (!staged) {            // defensive path: no LDS image (footprint larger than the buffer)
+      if (rot) {
+        const Tap t = rot_tap(rc, rs, i, j, n);
+        float m = 0.f; v[0] = v[1] = v[2] = 0.f;
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx) {
+            const int yy = t.y0 + dy, xx = t.x0 + dx;
+            if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
+            const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
+            m += w;
+            if (in_rect(a, yy, xx)) continue;
+            float q[3];
+            bicubic3(rgb, g, b, yy, xx, q);
+            v[0] += w * q[0]; v[1] += w * q[1]; v[2] += w * q[2];
+          }
+        v[0] *= m; v[1] *= m; v[2] *= m;
+      } else {
+        v[0] = v[1] = v[2] = 0.f;
+        if (!in_rect(a, i, j)) bicubic3(rgb, g, b, i, j, v);
+      }
+    } else if (rot) {
+      const Tap t = rot_tap(rc, rs, i, j, n);
+      float m = 0.f; v[0] = v[1] = v[2] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int yy = t.y0 + dy, xx = t.x0 + dx;
+          if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
+          const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
+          m += w;                                                               // sampled ones-mask (fill = 0)
+          v[0] += w * fp[0][yy - y0][xx - x0]; v[1] += w * fp[1][yy - y0][xx - x0]; v[2] += w * fp[2][yy - y0][xx - x0];
+        }
+      v[0] *= m; v[1] *= m; v[2] *= m;
+    } else {
+      v[0] = fp[0][li][lj]; v[1] = fp[1][li][lj]; v[2] = fp[2][li][lj];
+    }
+    if (pack) {
+      const int pl = ((li >> lp) * (kFT >> lp) + (lj >> lp)) * (3 << (2 * lp)) + ((li & (p - 1)) << lp) + (lj & (p - 1));
+      stg[pl] = (half_t)((v[0] - kClipMean[0]) / kClipStd[0]);
+      stg[pl + (1 << (2 * lp))] = (half_t)((v[1] - kClipMean[1]) / kClipStd[1]);
+      stg[pl + (2 << (2 * lp))] = (half_t)((v[2] - kClipMean[2]) / kClipStd[2]);
+    } else {
+      emit3<OUT>(out, s, i, j, n, p, v[0], v[1], v[2]);
+    }
+  }
+  if (pack) {
+    __syncthreads();
+    const int per = 3 << (2 * lp);                       // halfs per patch (a multiple of 8 for p >= 4)
+    half_t* o = reinterpret_cast<half_t*>(out);
+    for (int ch = threadIdx.x; ch < 3 * kFT * kFT / 8; ch += blockDim.x) {
+      const int e = ch * 8, lpatch = e / per, off = e - lpatch * per;
+      const int pi = lpatch / (kFT >> lp), pj = lpatch - pi * (kFT >> lp);
+      const size_t base = patch_index(s, 0, ti0 + (pi << lp), tj0 + (pj << lp), n, p);
+      *reinterpret_cast<half8*>(o + base + off) = *reinterpret_cast<const half8*>(stg + e);
+    }
   }
 }
 
@@ -612,8 +770,8 @@ static int check_geom(const aph_sample_geom* g, int out_mode, const char* who, i
   if (g->S < 1 || g->size < 1 || g->H < 1 || g->W < 1 || g->Hp < g->H || g->Wp < g->W)
     return aph_fail(APH_ERR_ARG, "%s: bad geometry S=%d size=%d H=%d W=%d Hp=%d Wp=%d", who, g->S, g->size, g->H, g->W, g->Hp, g->Wp);
   if (out_mode < 0 || out_mode > max_mode) return aph_fail(APH_ERR_ARG, "%s: bad out_mode %d", who, out_mode);
-  if (out_mode >= APH_OUT_PATCH_F16 && (g->patch < 1 || g->size % g->patch))
-    return aph_fail(APH_ERR_ARG, "%s: size %d not divisible by patch %d", who, g->size, g->patch);
+  if (out_mode >= APH_OUT_PATCH_F16 && (g->patch < 1 || g->size % g->patch || (g->patch & (g->patch - 1))))
+    return aph_fail(APH_ERR_ARG, "%s: size %d not divisible by patch %d, or patch not a power of two", who, g->size, g->patch);
   return APH_OK;
 }
 
@@ -655,18 +813,26 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   const int n = g.size;
   const dim3 grid((n * n + 255) / 256, g.S), block(256);
   if (!aug) {
-    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g);
-    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, rgb, (const int*)table, out, g);
-    else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g);
+    const float* none = nullptr;
+    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
+    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
+    else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
     return aph_check_launch("aph_sample_fwd");
   }
   float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
   float* Bv = A + scratch_floats(g);
-  APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g);
+  // cuts without a perspective: one fused kernel, no scratch
+  const int tiles = (n + kFT - 1) / kFT;
+  const dim3 fgrid(tiles * tiles, g.S);
+  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_NCHW_RAW>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
+  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_NCHW_NORM>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
+  else APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_PATCH_F16>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
+  // cuts with a perspective (p = 0.2): resized cut -> A, perspective A -> B, erase + rotation B -> out (workgroups of the other cuts exit at once)
+  APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g, aug);
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
-  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
-  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
-  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
+  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
+  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
+  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
   return aph_check_launch("aph_sample_fwd");
   APH_CATCH
 }

@@ -372,6 +372,13 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
   APH_CATCH
 }
 
+// MFMA shape of every GEMM main loop launched from now on: 1 = 32x32x16 (default), 0 = 16x16x32.  Returns the previous value.
+int aph_gemm_set_mfma32(int on) {
+  const int prev = gemm_mfma32();
+  gemm_mfma32() = on ? 1 : 0;
+  return prev;
+}
+
 // plain C = A * Bt^T (f16 in, f32 out) -- exported for the GEMM unit tests and micro-benchmarks
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream_) {
   APH_TRY

@@ -90,7 +90,35 @@ struct SplitK {
   int splits;
 };
 
-template <class C, class Epi, bool SK = false>
+// 32x32x16 fragments of the same LDS image: row tile t (32 rows), k16 sub-step u of k32-step ks -> 16-byte chunk 4 ks + 2 u + (lane >> 5)
+template <class C>
+struct GemmFrags32 {
+  half8 a[C::TM / 2][2], b[C::TN / 2][2];
+};
+template <class C>
+__device__ __forceinline__ void gemm_load_frags32(GemmFrags32<C>& f, const half_t* As, const half_t* Bs, int arow, int brow, int chunk0) {
+#pragma unroll
+  for (int t = 0; t < C::TM / 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) f.a[t][u] = *reinterpret_cast<const half8*>(As + lds_off(arow + t * 32, chunk0 + 2 * u));
+#pragma unroll
+  for (int t = 0; t < C::TN / 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) f.b[t][u] = *reinterpret_cast<const half8*>(Bs + lds_off(brow + t * 32, chunk0 + 2 * u));
+}
+template <class C>
+__device__ __forceinline__ void gemm_mma32(f32x16 (&acc)[C::TM / 2][C::TN / 2], const GemmFrags32<C>& f) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int mt = 0; mt < C::TM / 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::TN / 2; ++nt) acc[mt][nt] = mfma_32x32x16_f16(f.b[nt][u], f.a[mt][u], acc[mt][nt]);
+}
+
+// M32: the main loop runs on v_mfma_f32_32x32x16_f16 (half the MFMA instructions per k-tile; same LDS image, same DMA
+// schedule, same epilogue reads) instead of v_mfma_f32_16x16x32_f16
+template <class C, class Epi, bool SK = false, bool M32 = false>
 __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
                                                               int ldb, int M, int N, int K, Epi epi, SplitK sk) {
   APH_DYN_SMEM(smem);
@@ -140,23 +168,46 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     for (int k = 0; k < C::GB; ++k) glds16(gb[k] + ko, Bs + (wave * C::GB + k) * 8 * GEMM_BK);
   };
 
-  f32x4 acc[C::TM][C::TN];
+  static_assert(!M32 || (C::TM % 2 == 0 && C::TN % 2 == 0 && C::EP_MT == C::TM), "32x32 fragments need even tile counts and a one-pass epilogue");
+  f32x4 acc[M32 ? 1 : C::TM][M32 ? 1 : C::TN];
+  f32x16 acc32[M32 ? C::TM / 2 : 1][M32 ? C::TN / 2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i)
+    for (int i = 0; i < C::TM / 2; ++i)
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < C::TN / 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  const int arow = wm * C::TM * 16 + (lane & 15), brow = wn * C::TN * 16 + (lane & 15), fchunk = lane >> 4;
+  const int frow = M32 ? (lane & 31) : (lane & 15);
+  const int arow = wm * C::TM * 16 + frow, brow = wn * C::TN * 16 + frow, fchunk = M32 ? (lane >> 5) : (lane >> 4);
   // Ring protocol, tile t lives in stage t % NSTAGE.  Per tile kt: own DMAs of tile kt retired (counted vmcnt: newer
   // tiles stay in flight) -> s_barrier (everyone's retired; everyone's fragment reads of tile kt-1 are complete, so
   // its stage may be refilled) -> issue tile kt-1+NSTAGE -> read fragments of tile kt.
   GemmFrags<C> f0, f1;
+  GemmFrags32<C> g0, g1;
+  auto load0 = [&](const half_t* As_) {                 // k32-step 0 of a tile
+    if constexpr (M32) gemm_load_frags32<C>(g0, As_, As_ + C::BM * GEMM_BK, arow, brow, fchunk);
+    else gemm_load_frags<C>(f0, As_, As_ + C::BM * GEMM_BK, arow, brow, fchunk);
+  };
+  auto load1 = [&](const half_t* As_) {                 // k32-step 1
+    if constexpr (M32) gemm_load_frags32<C>(g1, As_, As_ + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
+    else gemm_load_frags<C>(f1, As_, As_ + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
+  };
+  auto mma0 = [&]() { if constexpr (M32) gemm_mma32<C>(acc32, g0); else gemm_mma<C>(acc, f0); };
+  auto mma1 = [&]() { if constexpr (M32) gemm_mma32<C>(acc32, g1); else gemm_mma<C>(acc, f1); };
 #pragma unroll
   for (int t = 0; t < C::NSTAGE - 1; ++t)
     if (t < nk) issue(t, t);
   ring_wait<C>((nk - 1 < C::NSTAGE - 2) ? nk - 1 : C::NSTAGE - 2);
   if (C::NSTAGE - 1 < nk) issue(C::NSTAGE - 1, C::NSTAGE - 1);
-  gemm_load_frags<C>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
+  load0(lds);
   int st_cur = 0;
   const bool late = wave >= C::NWAVE / 2;      // the SIMD partner of wave w - NWAVE/2: issues its DMA half a k-tile later
   for (int kt = 0; kt < nk; ++kt) {
@@ -164,16 +215,15 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     const int st_free = st_cur;
     st_cur = st_cur == C::NSTAGE - 1 ? 0 : st_cur + 1;
     const int rem = nk - 2 - kt;
-    gemm_load_frags<C>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);   // k-step 1 of tile kt: in flight during the MFMAs
-    gemm_mma<C>(acc, f0);                                                      // k-step 0 of tile kt
+    load1(As);                                                                 // k-step 1 of tile kt: in flight during the MFMAs
+    mma0();                                                                    // k-step 0 of tile kt
     if (kt + 1 < nk) {
       wait_lgkm0();                                                            // f1 has left LDS: stage st_free is dead for this wave
       ring_wait<C>(rem < C::NSTAGE - 2 ? rem : C::NSTAGE - 2);
       if (!late && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
-      const half_t* An = lds + st_cur * C::STAGE;
-      gemm_load_frags<C>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);     // k-step 0 of tile kt+1: overlaps the MFMAs below
+      load0(lds + st_cur * C::STAGE);                                          // k-step 0 of tile kt+1: overlaps the MFMAs below
     }
-    gemm_mma<C>(acc, f1);                                                      // k-step 1 of tile kt
+    mma1();                                                                    // k-step 1 of tile kt
     if (late && kt + 1 < nk && kt + C::NSTAGE < nk) issue(kt + C::NSTAGE, st_free);
   }
   // Epilogue through LDS: every wave parks its fp32 accumulator tile in its own slice of the (now idle) ring, then each
@@ -185,11 +235,22 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
 #pragma unroll
   for (int p0 = 0; p0 < C::TM; p0 += C::EP_MT) {
     wave_lds_fence();
+    if constexpr (M32) {       // D[n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][m = lane & 31]: four runs of 4 consecutive columns per lane
 #pragma unroll
-    for (int mt = 0; mt < C::EP_MT; ++mt)
+      for (int mt = 0; mt < C::TM / 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < C::TN; ++nt)
-        *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+        for (int nt = 0; nt < C::TN / 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(ct + (mt * 32 + (lane & 31)) * C::CT_LD + nt * 32 + 8 * g + 4 * (lane >> 5)) =
+                f32x4{acc32[mt][nt][4 * g], acc32[mt][nt][4 * g + 1], acc32[mt][nt][4 * g + 2], acc32[mt][nt][4 * g + 3]};
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < C::EP_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::TN; ++nt)
+          *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+    }
     wave_lds_fence();
 #pragma unroll
     for (int it = 0; it < C::EP_MT * 16 / RPI; ++it) {
@@ -261,7 +322,7 @@ __device__ __forceinline__ void mfma_prio(int on) {
 #endif
 }
 
-template <class Epi>
+template <class Epi, bool M32 = false>
 __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb,
                                                         int M, int N, int K, Epi epi) {
   using C = Gemm8;
@@ -308,34 +369,67 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
     for (int i = 0; i < 2; ++i) glds16(gB[i] + (h ? bhalf : 0) + kt * GEMM_BK, stage + dB[h][i]);
   };
 
-  f32x4 acc[8][4];
+  // accumulators and fragments: 16x16x32 -> acc[8][4] f32x4, A [row tile 16][k32 step], B [half][col tile 16][k32 step];
+  //                             32x32x16 -> acc32[4][2] f32x16, A [row tile 32][k16 step], B [half][k16 step] (one 32-col tile per half)
+  f32x4 acc[M32 ? 1 : 8][M32 ? 1 : 4];
+  f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  half8 fa[4][2], fb[2][2][2];       // A: [row tile][k step] of the current half; B: [half][col tile][k step]
-  const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15), fchunk = lane >> 4;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  half8 fa[4][2], fb[2][2][2];
+  half8 ga[2][4], gb[2][4];
+  const int frow = M32 ? (lane & 31) : (lane & 15);
+  const int arow = wr * 128 + frow, brow = wc * 64 + frow, fchunk = M32 ? (lane >> 5) : (lane >> 4);
   auto read_a = [&](int h, const half_t* stage) {
+    if constexpr (M32) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fa[t][ks] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 16, ks * 4 + fchunk));
+        for (int u = 0; u < 4; ++u) ga[t][u] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 32, 2 * u + fchunk));
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[t][ks] = *reinterpret_cast<const half8*>(stage + lds_off(arow + h * 64 + t * 16, ks * 4 + fchunk));
+    }
   };
   auto read_b = [&](int h, const half_t* stage) {
+    if constexpr (M32) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int u = 0; u < 4; ++u) gb[h][u] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32, 2 * u + fchunk));
+    } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        fb[h][t][ks] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32 + t * 16, ks * 4 + fchunk));
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fb[h][t][ks] = *reinterpret_cast<const half8*>(stage + C::BM * GEMM_BK + lds_off(brow + h * 32 + t * 16, ks * 4 + fchunk));
+    }
   };
   auto quadrant = [&](int ah, int bh) {
     mfma_prio(1);
+    if constexpr (M32) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt) acc32[ah * 2 + mt][bh] = mfma_32x32x16_f16(gb[bh][u], ga[mt][u], acc32[ah * 2 + mt][bh]);
+    } else {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[ah * 4 + mt][bh * 2 + nt] = mfma_16x16x32_f16(fb[bh][nt][ks], fa[mt][ks], acc[ah * 4 + mt][bh * 2 + nt]);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[ah * 4 + mt][bh * 2 + nt] = mfma_16x16x32_f16(fb[bh][nt][ks], fa[mt][ks], acc[ah * 4 + mt][bh * 2 + nt]);
+    }
     mfma_prio(0);
   };
 
@@ -378,11 +472,20 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
 #pragma unroll
   for (int p0 = 0; p0 < 8; p0 += C::EP_MT) {
     wave_lds_fence();
+    if constexpr (M32) {
 #pragma unroll
-    for (int mt = 0; mt < C::EP_MT; ++mt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(ct + (lane & 31) * C::CT_LD + nt * 32 + 8 * g + 4 * (lane >> 5)) =
+              f32x4{acc32[p0 / 2][nt][4 * g], acc32[p0 / 2][nt][4 * g + 1], acc32[p0 / 2][nt][4 * g + 2], acc32[p0 / 2][nt][4 * g + 3]};
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < C::EP_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+    }
     wave_lds_fence();
 #pragma unroll
     for (int it = 0; it < C::EP_MT * 2; ++it) {
@@ -480,11 +583,19 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
   }
 };
 
+// MFMA shape of the main loops: 1 = v_mfma_f32_32x32x16_f16 (default), 0 = v_mfma_f32_16x16x32_f16 (aph_gemm_set_mfma32: A/B measurements)
+inline int& gemm_mfma32() { static int v = 1; return v; }
+
 template <class C, class Epi>
 inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false>), C::SMEM);
-  APH_LAUNCH((gemm_f16_kernel<C, Epi, false>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt,
-             ldb, M, N, K, epi, SplitK{nullptr, 1});
+  const dim3 grid((N / C::BN) * ((M + C::BM - 1) / C::BM));
+  if (gemm_mfma32()) {
+    APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false, true>), C::SMEM);
+    APH_LAUNCH((gemm_f16_kernel<C, Epi, false, true>), grid, dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, SplitK{nullptr, 1});
+  } else {
+    APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false, false>), C::SMEM);
+    APH_LAUNCH((gemm_f16_kernel<C, Epi, false, false>), grid, dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, SplitK{nullptr, 1});
+  }
 }
 
 // split-K workspace of one caller (the ViT handle owns one; the partials of a launch are consumed by the reduce kernel
@@ -509,19 +620,30 @@ inline int choose_splits(int M, int N, int K, const SplitKSpace* sp) {
 template <class C, class Epi>
 inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, int splits,
                                const SplitKSpace& sp, hipStream_t st) {
-  APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true>), C::SMEM);
   const int tiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
-  APH_LAUNCH((gemm_f16_kernel<C, Epi, true>), dim3(tiles * splits), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi,
-             SplitK{sp.ws, splits});
+  if (gemm_mfma32()) {
+    APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true, true>), C::SMEM);
+    APH_LAUNCH((gemm_f16_kernel<C, Epi, true, true>), dim3(tiles * splits), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi,
+               SplitK{sp.ws, splits});
+  } else {
+    APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, true, false>), C::SMEM);
+    APH_LAUNCH((gemm_f16_kernel<C, Epi, true, false>), dim3(tiles * splits), dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi,
+               SplitK{sp.ws, splits});
+  }
   const size_t work = (size_t)M * (N / 8);
   APH_LAUNCH((splitk_reduce_kernel<Epi>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (const float*)sp.ws, splits, M, N, epi);
 }
 
 template <class Epi>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  APH_ALLOW_SMEM((gemm8_f16_kernel<Epi>), Gemm8::SMEM);
-  APH_LAUNCH((gemm8_f16_kernel<Epi>), dim3((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM)), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st,
-             A, lda, Bt, ldb, M, N, K, epi);
+  const dim3 grid((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM));
+  if (gemm_mfma32()) {
+    APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, true>), Gemm8::SMEM);
+    APH_LAUNCH((gemm8_f16_kernel<Epi, true>), grid, dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi);
+  } else {
+    APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, false>), Gemm8::SMEM);
+    APH_LAUNCH((gemm8_f16_kernel<Epi, false>), grid, dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi);
+  }
 }
 
 // tile choice, from the measured sweep over the ViT-B shapes at 1/2/4/8-rank shard sizes (tools/exp/tune_table.py):

@@ -36,8 +36,8 @@ def shard_range(S, rank, world):
 class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
-                 size=None, rank=0, world=1, process_group=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None):
+                 size=None, rank=0, world=1, process_group=None, comm=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -57,6 +57,10 @@ class Engine:
         if self.S < 1:
             raise ValueError('Engine: samples = %d; at least one cut is needed (upstream: torch.cat of an empty list, utils.py:253)' % self.S)
         self.rank, self.world, self.pg = rank, world, process_group
+        # comm: aphantasia_amd.comm.Comm -- RCCL called directly through the C ABI (aph_allreduce_f32) on the step's own stream.
+        # Without one the reduction goes through torch.distributed's group (the gloo / CPU test path).
+        self.comm = comm
+        self._reduce = world > 1 or (bool(reduce_always) and comm is not None)    # reduce_always: run the collective on a 1-rank communicator too (tests)
         self.lo, self.hi = shard_range(self.S, rank, world)
         self.S_loc = self.hi - self.lo
         self.sim = sim
@@ -74,8 +78,8 @@ class Engine:
         # measure the same step time at every shard size).  Multi-rank runs launch eagerly: graph replays next to a
         # collective backend's streams gave NaN / wrong gradients after the mid-run barrier + device synchronize that
         # bench.py performs (reproduced with gloo on one device and with RCCL at world size 1; eager launches never did).
-        if world > 1:
-            use_graph = False
+        if world > 1 and not (comm is not None and os.environ.get('APH_MULTIRANK_GRAPH') == '1'):
+            use_graph = False          # APH_MULTIRANK_GRAPH=1: the whole step INCLUDING the RCCL all-reduce and Adam as one graph
         self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
@@ -370,9 +374,10 @@ class Engine:
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._enqueue_grad(None)
-            if self.world == 1:
-                self._enqueue_adam()
-        self._graphs = (g1, None)          # world > 1: the Adam launch follows the all-reduce eagerly (one kernel)
+            if self._reduce:
+                self._all_reduce()         # (only with a direct RCCL comm: the collective is a node of the step's graph)
+            self._enqueue_adam()
+        self._graphs = (g1, None)
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
@@ -411,26 +416,32 @@ class Engine:
         if use_graph and self._graphs is not None:
             self._graphs[0].replay()
             self.visual._generation += 1
-            if self.world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
-                self._enqueue_adam()
             return self.loss
         self._enqueue_grad(shift)
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)      # the one collective of the step
+        if self._reduce:
+            self._all_reduce()
         self._enqueue_adam()
         return self.loss
+
+    def _all_reduce(self):
+        """the one collective of the step: sum of the partial parameter gradients over the ranks"""
+        if self.comm is not None:
+            self.comm.all_reduce_(self.grad, ops._stream(self.grad))
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
 
     def global_loss(self):
         """The step's loss summed over ranks (host float; synchronises)."""
         if self.world > 1:
-            import torch.distributed as dist
             t = self.loss.clone()
             if self.sim and 'ang' in str(self.sim) and self.rank != 0:
                 t -= sum(self.coef)          # the constant of 'ang' is counted once
-            dist.all_reduce(t, group=self.pg)
+            if self.comm is not None:
+                self.comm.all_reduce_(t)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(t, group=self.pg)
             return float(t)
         return float(self.loss)
 

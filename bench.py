@@ -144,6 +144,16 @@ def main():
     from aphantasia_amd import clip as aclip, transforms
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.clip import LOSS_SCALE
+    # the step's collective: RCCL called directly through the C ABI (aph_allreduce_f32); torch.distributed only carried the
+    # 128-byte unique id and does the barriers / the MAX over ranks of the timing contract.  APH_COMM=torch: all-reduce through
+    # torch.distributed instead (cross-check)
+    comm = None
+    if world > 1 and backend == 'nccl' and os.environ.get('APH_COMM', 'rccl') == 'rccl':
+        from aphantasia_amd import comm as acomm
+        try:
+            comm = acomm.create(rank, world)
+        except Exception as e:                 # keep the run alive on the torch.distributed path, loudly
+            print('bench.py rank %d: direct RCCL communicator failed (%s); falling back to torch.distributed.all_reduce' % (rank, e), file=sys.stderr, flush=True)
     w, h = [int(s) for s in cfg['size'].split('-')]
     dualmod = cfg.get('dualmod')
     S = derate(cfg['samples'], cfg['model'], cfg['transform'], dualmod)
@@ -163,7 +173,7 @@ def main():
         trf = transforms.transforms_fast if transform_name == 'fast' else transforms.normalize()
         torch.manual_seed(0)
         np.random.seed(0)
-        kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, use_graph=not a.no_graph)
+        kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, comm=comm, use_graph=not a.no_graph)
         if cfg.get('dwt'):
             from aphantasia_amd.image import dwt_image
             params, image_f, _ = dwt_image([1, 3, h, w], cfg['dwt'], 0.3, 1.8, None)
@@ -316,7 +326,8 @@ def main():
                                    'Adam(lr .05, b1 0), per-step image save off' % (a.config.upper(), w, h, kind, cfg['model'],
                                                                                     ' + ViT-B/16 every %d steps (--dualmod)' % dualmod if dualmod else '',
                                                                                     cfg['samples'], S, cfg['transform'], sim),
-                       'note': cfg['note'], 'samples_effective': S, 'parallelism': 'samples split over %d rank(s), 1 all-reduce/step' % world,
+                       'note': cfg['note'], 'samples_effective': S,
+                       'parallelism': 'samples split over %d rank(s), 1 all-reduce/step (%s)' % (world, 'none' if world == 1 else ('RCCL direct, aph_allreduce_f32' if comm is not None else 'torch.distributed ' + backend)),
                        'loss_scale': LOSS_SCALE, 'final_loss': loss, 'algorithmic_tflop_per_step': flop_step,
                        'lib_sha256': lib_sha()[:16]},
             'legs': legs, 'roofline': roof, 'cpu_baseline': cpu,

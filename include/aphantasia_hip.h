@@ -25,6 +25,7 @@ extern "C" {
 #define APH_ERR_HIP (-2)
 #define APH_ERR_UNSUPPORTED (-3)
 #define APH_ERR_INTERNAL (-4)
+#define APH_ERR_COMM (-5)      /* RCCL error */
 
 int aph_version(void);
 const char* aph_last_error(void);
@@ -174,6 +175,19 @@ int aph_adam_step(float* d_p, const float* d_g, float* d_m, float* d_v, float* d
  * caller, who lowers its loss scale when the count moves. */
 int aph_adam_step_guarded(float* d_params, const float* d_grad, float* d_m, float* d_v, float* d_vmax, const float* d_hyper8,
                           int decoupled_wd, size_t n, int* d_guard2, void* stream);
+
+/* ---- multi-GPU: the one collective of the step (the reference is single-GPU) ------------
+ * Samples are split over the ranks of one node (one process per GPU); every rank forms its partial spectrum gradient
+ * and ONE all-reduce (sum, f32) per step makes it the global gradient before the (replicated) Adam update.  RCCL is
+ * called directly and bound at run time; torch.distributed is not on the data path.
+ *   rank 0: aph_comm_unique_id(h_uid128) -> ship the 128 bytes to the other ranks (file, env, socket: the caller's choice);
+ *   every rank, with its GPU current: aph_comm_init(rank, nranks, h_uid128, &comm);
+ *   per step: aph_allreduce_f32(comm, d_buf, n, stream) -- in place, asynchronous on `stream`, capturable into a hipGraph. */
+typedef struct aph_comm aph_comm;
+int aph_comm_unique_id(void* h_uid128);
+int aph_comm_init(int rank, int nranks, const void* h_uid128, aph_comm** out);
+int aph_allreduce_f32(aph_comm* comm, float* d_buf, size_t n, void* stream);
+int aph_comm_destroy(aph_comm* comm);
 
 #ifdef __cplusplus
 }

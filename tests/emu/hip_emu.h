@@ -221,6 +221,7 @@ inline unsigned long long __ballot(int pred) {
   return m;
 }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline void __threadfence() {}
 inline float __expf(float x) { return expf(x); }

@@ -165,6 +165,9 @@ def check_sampler_augment(lib, dev, H=40, W=48, S=6, size=16, patch=8):
     tb = torch.from_numpy(table).to(dev)
     out = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=aug, lib=lib)
     assert (out.cpu() - cuts.detach()).abs().max().item() < 3e-4
+    # the patch-major f16 emit (LDS-staged 16-byte stores for full tiles) holds the same values
+    pm = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=aug, out_mode=_ffi.APH_OUT_PATCH_F16, lib=lib)
+    assert torch.equal(pm.cpu(), to_patch_major(out.cpu(), patch).half())
     got = ops.sample_bwd(geom, gout.to(dev).contiguous(), tb, aug=aug, lib=lib)
     assert (got.cpu() - img.grad[0]).abs().max().item() < 3e-4 * img.grad.abs().max().item()
 
@@ -274,14 +277,21 @@ def check_adam(lib, dev, n=5000):
             assert (p.cpu() - q.detach()).abs().max().item() < 2e-6, name
 
 
-def check_gemm(lib, dev, shapes, tile_cfg=0):
+def check_gemm(lib, dev, shapes, tile_cfg=0, variants=(1, 0)):
+    """variants: MFMA shape of the main loop, 1 = 32x32x16 (the default), 0 = 16x16x32 -- both are checked"""
+    L = lib if lib is not None else _ffi.lib()
     gen = torch.Generator().manual_seed(0)
     for (M, Nn, K) in shapes:
         A = torch.randn(M, K, generator=gen).half()
         Bt = torch.randn(Nn, K, generator=gen).half()       # asymmetric operands (catches transposes)
-        C = ops.gemm_f16(A.to(dev), Bt.to(dev), lib=lib, tile_cfg=tile_cfg)
         want = A.float() @ Bt.float().T
-        assert (C.cpu() - want).abs().max().item() < 2e-3 * (K / 64) ** 0.5, (M, Nn, K)
+        for v in variants:
+            prev = L.cdll.aph_gemm_set_mfma32(v)
+            try:
+                C = ops.gemm_f16(A.to(dev), Bt.to(dev), lib=lib, tile_cfg=tile_cfg)
+            finally:
+                L.cdll.aph_gemm_set_mfma32(prev)
+            assert (C.cpu() - want).abs().max().item() < 2e-3 * (K / 64) ** 0.5, (M, Nn, K, v)
 
 
 TINY = dict(input_resolution=32, patch_size=16, width=256, layers=2, heads=4, output_dim=128)

@@ -57,6 +57,7 @@ def test_sampler_adjoint(emu, align, mode):
 
 def test_sampler_augment(emu):
     K.check_sampler_augment(emu, 'cpu')
+    K.check_sampler_augment(emu, 'cpu', H=80, W=96, S=6, size=64, patch=16)      # full 32x32 tiles: LDS-staged patch-major emit
 
 
 def test_augment_invariants(emu):

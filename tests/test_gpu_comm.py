@@ -1,0 +1,110 @@
+"""GPU: the direct RCCL collective behind the C ABI (aph_comm_* / aph_allreduce_f32).
+One-rank communicator on any box (the all-reduce is then the identity, but it is a real RCCL launch: eager, and as a node
+of the step's hipGraph next to a mid-run device synchronize -- the pattern that broke the torch.distributed + graph-replay
+combination in round 1); two ranks when the box has two GPUs (skipped on the 1-GPU boxes)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def test_one_rank_allreduce_and_error_convention():
+    from aphantasia_amd import comm as acomm
+    uid = acomm.new_unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = acomm.Comm(0, 1, uid)
+    x = torch.randn(2769120, device=DEV)
+    y = x.clone()
+    c.all_reduce_(y)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        c.all_reduce_(x.half())
+    with pytest.raises(RuntimeError):
+        acomm.Comm(3, 2, uid)                  # rank outside 0..nranks-1: APH_ERR_ARG, no RCCL call
+    c.close()
+
+
+def test_step_with_in_graph_allreduce_matches_plain_step():
+    """whole step (gradient + RCCL all-reduce + Adam) captured as ONE hipGraph, a device synchronize in the middle of the run:
+    bit-identical to the engine without a communicator"""
+    from aphantasia_amd import clip as aclip, comm as acomm, transforms
+    from aphantasia_amd.engine import Engine
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model, _ = aclip.load('ViT-B/32', seed=1, max_batch=24)
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    c = acomm.Comm(0, 1, acomm.new_unique_id())
+
+    def run(comm, graph):
+        seed_all(0)
+        h, w = 360, 640
+        params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+        eng = Engine(params, h, w, model, 24, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=0.4, use_graph=graph,
+                     comm=comm, reduce_always=comm is not None)
+        losses = []
+        for i in range(8):
+            losses.append(eng.step())
+            if i == 4:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return eng.params.clone(), eng.grad.clone(), [float(l) for l in losses[-1:]]
+    a = run(None, False)
+    b = run(c, False)
+    d = run(c, True)
+    for x, y in ((a, b), (a, d)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and x[2] == y[2]
+    assert torch.isfinite(a[0]).all()
+
+
+def _rank_main(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), APH_RUN_ID='t%d' % port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    from aphantasia_amd import clip as aclip, comm as acomm, transforms
+    from aphantasia_amd.engine import Engine
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model, _ = aclip.load('ViT-B/32', seed=1, max_batch=24)
+    c = acomm.create(rank, world, key='t%d' % port) if world > 1 else None
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    seed_all(0)
+    h, w = 360, 640
+    params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).cuda().contiguous()
+    eng = Engine(params, h, w, model, 24, [(target, -1.0)], sim='mix', transform=transforms.normalize(), macro=0.4, rank=rank, world=world, comm=c,
+                 rng='reference')
+    losses = []
+    for i in range(6):
+        seed_all(100 + i)
+        eng.step()
+        losses.append(eng.global_loss())
+    torch.cuda.synchronize()
+    ret[rank] = (eng.params.cpu(), losses)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_two_ranks_bit_identical_params_and_loss_curve():
+    """R = 2 over RCCL: parameters bit-identical across ranks after every step's replicated Adam, loss curve equal to R = 1 to
+    fp32 rounding"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    ps = [ctx.Process(target=_rank_main, args=(r, 2, 29731, ret)) for r in range(2)]
+    for p in ps: p.start()
+    for p in ps: p.join(600)
+    assert len(ret) == 2
+    single = mgr.dict()
+    p = ctx.Process(target=_rank_main, args=(0, 1, 29733, single)); p.start(); p.join(600)
+    assert torch.equal(ret[0][0], ret[1][0])
+    assert ret[0][1] == ret[1][1]
+    assert np.abs(np.array(ret[0][1]) - np.array(single[0][1])).max() < 2e-5
