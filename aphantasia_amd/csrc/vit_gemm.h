@@ -24,6 +24,7 @@
 // (loads clamp the row, stores are predicated).
 #pragma once
 #include "aph_device.h"
+#include <cstdlib>
 
 namespace aph {
 
@@ -583,8 +584,15 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
   }
 };
 
-// MFMA shape of the main loops: 1 = v_mfma_f32_32x32x16_f16 (default), 0 = v_mfma_f32_16x16x32_f16 (aph_gemm_set_mfma32: A/B measurements)
-inline int& gemm_mfma32() { static int v = 1; return v; }
+// MFMA shape of the main loops: 1 = v_mfma_f32_32x32x16_f16, 0 = v_mfma_f32_16x16x32_f16.  Default below; the environment
+// variable APH_GEMM_MFMA32 (read once) or aph_gemm_set_mfma32() override it for A/B measurements.
+#ifndef APH_GEMM_MFMA32_DEFAULT
+#define APH_GEMM_MFMA32_DEFAULT 0
+#endif
+inline int& gemm_mfma32() {
+  static int v = [] { const char* e = getenv("APH_GEMM_MFMA32"); return e ? (atoi(e) != 0 ? 1 : 0) : APH_GEMM_MFMA32_DEFAULT; }();
+  return v;
+}
 
 template <class C, class Epi>
 inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
@@ -657,7 +665,8 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
-  if (N % Gemm8::BN == 0 && huge_tiles >= 400) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
+  static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)
+  if (N % Gemm8::BN == 0 && huge_tiles >= gemm8_min) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {

@@ -191,11 +191,13 @@ def check_augment_invariants(lib, dev, size=32, patch=16):
     #     result equals the normalize-only cuts to rounding (not bit for bit); the ones-mask is 1 to the same rounding.
     prm0 = [dict(persp=None, erase=None, angle=0.0) for _ in range(S)]
     out0 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm0).to(dev), lib=lib).cpu()
-    assert (out0 - plain).abs().max().item() < 5e-5
+    # (the grid's deviation from the pixel centres grows with the side: ~n x 2^-24 of a pixel, times the image gradient)
+    tol = 5e-5 * max(1.0, size / 32.0)
+    assert (out0 - plain).abs().max().item() < tol, (out0 - plain).abs().max().item()
     # (2) identity perspective + 0 degrees: same
     prm1 = [dict(persp=ident, erase=None, angle=0.0) for _ in range(S)]
     out1 = ops.sample_fwd(geom, rgb, tb, aug=pack_aug(prm1).to(dev), lib=lib).cpu()
-    assert (out1 - plain).abs().max().item() < 1e-4
+    assert (out1 - plain).abs().max().item() < 2 * tol, (out1 - plain).abs().max().item()
     # (3) erase: the rectangle [i, i+h) x [j, j+w) is 0 BEFORE normalisation, i.e. -mean/std after; everything else untouched
     rect = (3, 5, 7, 9)
     prm2 = [dict(persp=None, erase=rect, angle=None) for _ in range(S)]          # angle None: no rotation stage at all (has_rotation 0)

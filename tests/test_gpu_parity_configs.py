@@ -67,7 +67,7 @@ def target512(seed=2):
 
 
 def compare_grad(got, ref, cos_min, rel_max):
-    got, ref = got.reshape(-1).float().cpu(), ref.reshape(-1).float()
+    got, ref = got.reshape(-1).double().cpu(), ref.reshape(-1).double()
     cos = torch.nn.functional.cosine_similarity(got, ref, dim=0).item()
     rel = (got - ref).abs().max().item() / ref.abs().max().item()
     assert cos > cos_min and rel < rel_max, (cos, rel)
@@ -261,7 +261,7 @@ def test_loss_curve_stress_weights():
 # ------------------------------------------------------------------------------------------------ optional terms vs the oracle
 def test_sharp_expand_terms_vs_oracle(b32):
     """--sharp (clip_fft.py:269-270) and --expand (:276-280) in the fused engine vs the oracle's restatement, three steps"""
-    h, w, S, sharp, expand = 192, 256, 4, 0.6, 0.5
+    h, w, S, sharp, expand = 256, 320, 4, 0.6, 0.5          # (frames at least `size` tall: a cut never exceeds the image, utils.py:231,245)
     seed_all(0)
     p0 = R.fft_params_init([1, 3, h, w])
     tgt = target512()
@@ -281,7 +281,7 @@ def test_sharp_expand_terms_vs_oracle(b32):
 def test_enforce_term_vs_oracle(b32, tf):
     """--enforce (clip_fft.py:271-275): a second independently drawn slice_imgs, pairwise similarity with gradient into both
     encodings -- fused engine (forward B, backward B, recompute A, backward A) vs the oracle's autograd"""
-    h, w, S, enforce = 192, 256, 4, 0.7
+    h, w, S, enforce = 256, 320, 4, 0.7
     trf = transforms.normalize() if tf == 'none' else transforms.transforms_fast
     seed_all(0)
     p0 = R.fft_params_init([1, 3, h, w])
@@ -344,7 +344,7 @@ def test_illustrip_frame_loop_vs_oracle(b32, gen):
     the parameters from it and restart the optimiser -- engine (aph_frame_affine, aph_irfft2 / aph_rfft2, reset_params) vs the
     oracle's loop (restated T.functional.affine, torch.fft, a fresh torch.optim.Adam per frame)"""
     from aphantasia_amd import ops
-    h, w, S = 192, 256, 6
+    h, w, S = 256, 320, 6
     tgt = target512()
     motion = (2.0, (3, -1), 1.03, 1.0)             # angle, shift, scale, shear
     seed_all(0)

@@ -165,7 +165,8 @@ def test_full_size_properties(model):
 
 
 def test_dwt_and_pixel_engines_vs_autograd_api(model):
-    """dwt_image / pixel_image through the fused engine == the same step through the drop-in autograd API"""
+    """dwt_image / pixel_image through the fused engine == the same step through the drop-in autograd API
+    (orchestration check: both sides run the same kernels; parity with the oracle is in test_gpu_parity_configs.py)"""
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.image import dwt_image, pixel_image, to_valid_rgb
     from aphantasia_amd.utils import slice_imgs, sim_func
@@ -249,12 +250,13 @@ def test_cli_resume_from_image_and_pt(tmp_path):
 
 def test_sharp_and_expand_terms_vs_autograd_api(model):
     """clip_fft.py:269-270 (--sharp) and :276-280 (--expand) in the fused engine vs the same terms written with torch ops
-    on the drop-in autograd API, three Adam steps"""
+    on the drop-in autograd API, three Adam steps (orchestration check: same kernels on both sides; the oracle-based
+    version is test_gpu_parity_configs.py::test_sharp_expand_terms_vs_oracle)"""
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.image import fft_image, to_valid_rgb
     from aphantasia_amd.utils import slice_imgs, sim_func
     from aphantasia_amd import transforms
-    h, w, S, sharp, expand = 192, 256, 4, 0.6, 0.5
+    h, w, S, sharp, expand = 256, 320, 4, 0.6, 0.5
     target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
 
     def derivat_naiv(img):                      # utils.py:265-268
@@ -292,12 +294,13 @@ def test_sharp_and_expand_terms_vs_autograd_api(model):
 @pytest.mark.parametrize('tf', ['none', 'fast'])
 def test_enforce_term_vs_autograd_api(model, tf):
     """clip_fft.py:271-275 (--enforce): second independently drawn set of cuts, pairwise similarity with gradient into both
-    encodings -- fused engine (forward B, backward B, recompute A, backward A) vs torch autograd over the drop-in API"""
+    encodings -- fused engine (forward B, backward B, recompute A, backward A) vs torch autograd over the drop-in API
+    (orchestration check; oracle-based: test_gpu_parity_configs.py::test_enforce_term_vs_oracle)"""
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.image import fft_image, to_valid_rgb
     from aphantasia_amd.utils import slice_imgs, sim_func
     from aphantasia_amd import transforms
-    h, w, S, enforce = 192, 256, 4, 0.7
+    h, w, S, enforce = 256, 320, 4, 0.7
     trf = transforms.normalize() if tf == 'none' else transforms.transforms_fast
     target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
     seed_all(0)
@@ -369,7 +372,7 @@ def test_illustrip_frame_loop_reparameterisation(model, gen):
     indistinguishable from building a fresh engine on the warped parameters."""
     from aphantasia_amd.engine import Engine
     from aphantasia_amd import transforms
-    h, w, S = 192, 256, 6
+    h, w, S = 256, 320, 6
     target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
     kw = dict(sim='mix', transform=transforms.transforms_fast, macro=0.4, rng='reference')
     if gen == 'RGB':
