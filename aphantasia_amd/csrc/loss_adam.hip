@@ -139,6 +139,34 @@ __global__ void loss_reduce_kernel(const float* __restrict__ partial, int S, flo
 // can be replayed with new step / lr:  {lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt(bias_corr2), gradscale}
 // ---------------------------------------------------------------------------------
 // guard[0] = running count of skipped (overflowed) steps, guard[1] = "this step's gradient has a non-finite element"
+// Linear head on the encodings -- the aesthetic predictor of clip_fft.py:255-256 / utils.py:402-413
+// (`loss -= 0.001 * a.aest * aest(out_enc).mean()`, aest = nn.Linear(D, 1)):
+//   loss += coef * ( sum_s (w . enc_s + bias) ) / denom ,   genc[s][d] += gscale * coef * w[d] / denom
+// One workgroup; wave w takes cuts w, w + NW, ...; the per-cut dots are summed in cut order (deterministic).
+__global__ __launch_bounds__(256) void linear_head_kernel(const float* __restrict__ enc, int S, int D, const float* __restrict__ w,
+                                                          float bias, float coef, float denom, float gscale,
+                                                          float* __restrict__ loss, float* __restrict__ genc) {
+  APH_DYN_SMEM(smem);
+  float* dots = reinterpret_cast<float*>(smem);            // [S]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int s = wave; s < S; s += nw) {
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a += w[d] * enc[(size_t)s * D + d];
+    a = wave_sum(a);
+    if (lane == 0) dots[s] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += dots[s] + bias;
+    loss[0] += coef * t / denom;
+  }
+  if (genc) {
+    const float k = gscale * coef / denom;
+    for (int idx = threadIdx.x; idx < S * D; idx += blockDim.x) genc[idx] += k * w[idx % D];
+  }
+}
+
 __global__ void grad_guard_kernel(const float* __restrict__ g, size_t n, int* __restrict__ guard) {
   bool bad = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -207,6 +235,18 @@ int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const
   APH_LAUNCH(sim_loss_kernel, dim3(S), dim3(256), 0, st, d_enc, d_targets, d_coef, T, D, type, denom, gscale, d_ws, d_genc, lay);
   APH_LAUNCH(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)d_ws, S, denom, base, d_loss);
   return aph_check_launch("aph_sim_loss");
+  APH_CATCH
+}
+
+// Adds a linear head's term to a loss / encoding-gradient pair produced by aph_sim_loss (same denom / gscale conventions):
+// the aesthetic predictor, clip_fft.py:255-256 with coef = -0.001 * a.aest.  d_w [D] device, bias host scalar.
+int aph_linear_head(const float* d_enc, int S, int D, const float* d_w, float bias, float coef, float denom, float gscale,
+                    float* d_loss, float* d_genc, void* stream_) {
+  APH_TRY
+  if (!d_enc || !d_w || !d_loss || S < 1 || D < 1 || S > 16384 || !(denom > 0.f))
+    return aph_fail(APH_ERR_ARG, "aph_linear_head: bad argument (S=%d D=%d)", S, D);
+  APH_LAUNCH(linear_head_kernel, dim3(1), dim3(256), sizeof(float) * S, (hipStream_t)stream_, d_enc, S, D, d_w, bias, coef, denom, gscale, d_loss, d_genc);
+  return aph_check_launch("aph_linear_head");
   APH_CATCH
 }
 

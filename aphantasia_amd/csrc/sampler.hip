@@ -38,9 +38,14 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
 // four consecutive floats at 4-byte alignment: the compiler emits one global_load_dwordx4 (gfx950 handles the misalignment)
 struct __attribute__((packed, aligned(4))) F4u { float v[4]; };
 
+// v mod n for the wrap-tiled overscan frame (utils.py:165-167).  The padded frame is at most 2x the image (overmax), so
+// v lies in [-n, 2n): one conditional correction instead of an integer division (there are eight of these per output
+// pixel of the bicubic resize -- with `%` they were most of that kernel's instructions); the generic path is kept for safety.
 __device__ __forceinline__ int wrap(int v, int n) {
-  v %= n;
-  return v < 0 ? v + n : v;
+  if (v < 0) v += n;
+  else if (v >= n) v -= n;
+  if (v < 0 || v >= n) { v %= n; if (v < 0) v += n; }
+  return v;
 }
 
 // patch-major element offset of pixel (c,i,j) of cut s.  The patch side p is a power of two (checked on the host):
@@ -163,11 +168,10 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
 template <int OUT>
 __global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g,
                                    const float* __restrict__ only_persp) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   if (only_persp && only_persp[(size_t)s * APH_AUG_STRIDE + 8] == 0.f) return;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= g.size * g.size) return;
-  const int i = pix / g.size, j = pix - i * g.size;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);      // (no integer division per pixel)
+  if (i >= g.size || j >= g.size) return;
   const CutBox b = load_cut(table, s, g.size);
   float v[3];
   bicubic3(rgb, g, b, i, j, v);
@@ -445,12 +449,12 @@ __device__ __forceinline__ float warp_gather(const float* __restrict__ src, cons
 
 // stage 1: RandomPerspective for the cuts that drew it (A -> B); other cuts are skipped
 __global__ void persp_kernel(const float* __restrict__ A, const float* __restrict__ aug, float* __restrict__ Bo, int n) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n * n) return;
-  const int i = pix / n, j = pix - i * n;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= n || j >= n) return;
+  const int pix = i * n + j;
   const Tap t = persp_tap(a, i, j, n);
   for (int c = 0; c < 3; ++c) {
     const size_t pl = ((size_t)s * 3 + c) * n * n;
@@ -462,12 +466,12 @@ __global__ void persp_kernel(const float* __restrict__ A, const float* __restric
 template <int OUT>
 __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __restrict__ Bi, const float* __restrict__ aug,
                                    void* __restrict__ out, int n, int patch, int only_persp) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (only_persp && a[8] == 0.f) return;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n * n) return;
-  const int i = pix / n, j = pix - i * n;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= n || j >= n) return;
+  const int pix = i * n + j;
   const float* src = a[8] != 0.f ? Bi : A;
   if (a[15] != 0.f) {
     const Tap t = rot_tap(a[13], a[14], i, j, n);
@@ -520,9 +524,9 @@ __global__ __launch_bounds__(256) void crop_warp_fused_kernel(const float* __res
   const int FW = x1 - x0 + 1, FH = y1 - y0 + 1;
   const bool staged = FW >= 1 && FH >= 1 && FW <= kFMAX && FH <= kFMAX;      // always, for a rotation; else: taps straight from the image
   if (staged) {
-    const float c = 0.5f * (float)(n - 1);
+    const float c = 0.5f * (float)(n - 1), rfw = 1.0f / (float)FW;
     for (int idx = threadIdx.x; idx < FH * FW; idx += blockDim.x) {
-      const int fy = idx / FW, fx = idx - fy * FW, y = y0 + fy, x = x0 + fx;
+      const int fy = (int)(((float)idx + 0.5f) * rfw), fx = idx - fy * FW, y = y0 + fy, x = x0 + fx;      // exact for idx < 52 * 52
       if (rot) {
         // only pixels within two pixels of the tile's pre-image can be tapped: skip the corners of the bounding box
         const float ux = (float)x - c, uy = (float)y - c;
@@ -622,11 +626,11 @@ __device__ __forceinline__ float tap_hits(const Tap& t, int py, int px) {
 template <int OUT>
 __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const float* __restrict__ aug,
                                            float* __restrict__ dA, float* __restrict__ dB, int n, int patch) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n * n) return;
-  const int py = pix / n, px = pix - py * n;
+  const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (py >= n || px >= n) return;
+  const int pix = py * n + px;
   float* dst = a[8] != 0.f ? dB : dA;
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   if (!in_rect(a, py, px)) {
@@ -663,12 +667,12 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
 // Adjoint of stage 1 (perspective) as a gather: dB -> dA (in place of the cut's slot in dA).  Candidates =
 // bounding box of the inverse homography applied to the 2x2 square around p.
 __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* __restrict__ aug, float* __restrict__ dA, int n) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n * n) return;
-  const int py = pix / n, px = pix - py * n;
+  const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (py >= n || px >= n) return;
+  const int pix = py * n + px;
   // forward: (u, v) = H (x, y), x = j + .5, y = i + .5, source index = (u - .5, v - .5);  adj(H) maps back
   const float m00 = a[4] - a[5] * a[7], m01 = a[2] * a[7] - a[1], m02 = a[1] * a[5] - a[2] * a[4];
   const float m10 = a[5] * a[6] - a[3], m11 = a[0] - a[2] * a[6], m12 = a[2] * a[3] - a[0] * a[5];
@@ -811,7 +815,7 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
   const int n = g.size;
-  const dim3 grid((n * n + 255) / 256, g.S), block(256);
+  const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S), block(256);       // thread = (column, row) of a cut: 64 x 4 pixels per workgroup
   if (!aug) {
     const float* none = nullptr;
     if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
@@ -858,7 +862,7 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
   }
   float* dA = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
   float* dB = dA + scratch_floats(g);
-  const dim3 grid((n * n + 255) / 256, g.S);
+  const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);

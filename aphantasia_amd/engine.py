@@ -37,7 +37,7 @@ class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, comm=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False):
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False, aest=None):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -89,6 +89,11 @@ class Engine:
         self.loss_scale = float(LOSS_SCALE if loss_scale is None else loss_scale)
         self._guard_seen, self._guard_host, self._guard_ev = 0, None, None
         self.enforce = float(enforce)                               # clip_fft.py:271-275
+        # aest = (weight [D] or [1,D], bias, strength): `loss -= 0.001 * strength * (enc @ w + b).mean()` (clip_fft.py:255-256,
+        # utils.py:402-413: the LAION linear aesthetic predictor on the raw encodings)
+        self.aest = None
+        if aest is not None and float(aest[2]) != 0:
+            self.aest = (aest[0].detach().reshape(-1).float().to(self.dev).contiguous(), float(aest[1]), float(aest[2]))
         self.np_rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if rng == 'bulk' else None
         self.align, self.macro, self.transform = align, macro, transform
         self.cc = colcorr_t(colors).flatten().tolist()
@@ -242,6 +247,9 @@ class Engine:
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
                    len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), self.loss_scale, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
+            if self.aest is not None:
+                L.call('aph_linear_head', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.aest[0]), self.aest[1], -0.001 * self.aest[2],
+                       float(self.S), self.loss_scale, ops.ptr(self.loss), ops.ptr(self.genc), st)
             if self.enforce != 0:
                 self._enqueue_enforce(L, st, Sl)
             self.visual.handle.backward(self.genc, Sl, self.gpatch, vit_scale)

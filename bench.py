@@ -42,6 +42,8 @@ CONFIGS = {     # SURVEY.md section 8 config shorthand
     'c2': dict(size='1280-720', samples=200, model='ViT-B/32', transform='fast', macro=0.4, note='BASELINE configs[1] (the headline)'),
     'c3': dict(size='1280-720', samples=200, model='ViT-B/32', transform='fast', macro=0.4, dualmod=2, note='BASELINE configs[2]: --dualmod 2, ViT-B/32 <-> ViT-B/16 on one Adam state'),
     'c4': dict(size='3840-2160', samples=400, model='ViT-B/16', transform='fast', macro=0.4, dwt='db3', note='BASELINE configs[3]: --dwt -w db3, ViT-B/16'),
+    'c5': dict(size='1280-720', samples=100, model='ViT-B/32', transform='fast', macro=0.3, illustrip='RGB', align='overscan', colors=2.3, lr=0.1,
+               note='BASELINE configs[4] without the depth warp (no weights): illustrip continuous mode, --gen RGB, per frame = warp + re-parameterise + fresh Adam + 1 step'),
 }
 
 
@@ -174,7 +176,13 @@ def main():
         torch.manual_seed(0)
         np.random.seed(0)
         kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, comm=comm, use_graph=not a.no_graph)
-        if cfg.get('dwt'):
+        for k in ('align', 'colors', 'lr'):
+            if k in cfg:
+                kw[k] = cfg[k]
+        if cfg.get('illustrip'):          # illustrip.py:270-276,438-440: pixel parameters + brightness / contrast priors
+            leaf = (0.3 * torch.randn(1, 3, h, w)).to(dev).contiguous()
+            kw.update(param_kind='pixel', rgb_priors=True)
+        elif cfg.get('dwt'):
             from aphantasia_amd.image import dwt_image
             params, image_f, _ = dwt_image([1, 3, h, w], cfg['dwt'], 0.3, 1.8, None)
             leaf = image_f.flat
@@ -193,7 +201,15 @@ def main():
 
     def timed(e1, e2, steps, warmup, writer=None, tmpdir=None):
         """exactly `steps` steps between barrier + synchronize pairs; MAX over ranks"""
+        loop = None
+        if cfg.get('illustrip'):
+            from aphantasia_amd.illustrip_loop import FrameLoop
+            loop = FrameLoop(e1, gen=cfg['illustrip'], opt_step=1)
+
         def one(i):
+            if loop is not None:                 # one illustrip frame: MOTION + re-parameterisation + fresh optimiser + the step (illustrip.py:381-470)
+                loop.frame()
+                return
             e = e2 if (e2 is not None and i >= dualmod and i % dualmod == 0) else e1          # list(range(steps))[dm::dm], clip_fft.py:135
             e.step()
             if writer is not None:                                                             # clip_fft.py:297-306 (opt_step = 1)
@@ -284,7 +300,7 @@ def main():
             roof = dict(roof or {}, irdwt=roof_dwt)
 
     legs = None
-    if world == 1 and not a.no_legs and a.config in ('c2', 'c3', 'c4') and cfg['transform'] == 'fast':
+    if world == 1 and not a.no_legs and a.config in ('c2', 'c3', 'c4') and cfg['transform'] == 'fast' and not cfg.get('illustrip'):
         legs = {}
         e_n, e_nb = make('none', S_none)
         dtn = timed(e_n, e_nb, a.steps, a.warmup)
@@ -309,14 +325,14 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        if cfg.get('dwt') or dualmod is not None:
+        if cfg.get('dwt') or dualmod is not None or cfg.get('illustrip'):
             cpu = None          # the oracle leg is defined for the FFT single-model step; C3 / C4 lines report the GPU side only
         else:
             cpu = cpu_baseline(w, h, cfg['model'], S)
 
     if rank == 0:
         steps_per_s = a.steps / dt
-        kind = 'DWT %s' % cfg['dwt'] if cfg.get('dwt') else 'FFT'
+        kind = 'DWT %s' % cfg['dwt'] if cfg.get('dwt') else ('RGB-pixel (illustrip frame loop)' if cfg.get('illustrip') else 'FFT')
         out = {
             'metric': 'optimization steps/sec @%dx%d %s samples=%d' % (w, h, cfg['model'], cfg['samples']),
             'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,

@@ -7,9 +7,9 @@ format.  Additive flags: --clip-weights PATH (OpenAI CLIP checkpoint; without it
 weights are used and the pictures are meaningless), --seed N (seeds torch + numpy; the reference is
 unseeded), --no_save (skip the per-step JPEG, for timing).
 
-The standard loss (text / style / subtract prompts and a reference image, any --sim) runs through the
-fused HIP engine (aphantasia_amd/engine.py); --sharp / --enforce / --expand / --aest / --sync use the
-autograd drop-in API (aphantasia_amd.image / .utils / .clip) exactly like reference-style user code.
+The whole loss -- text / style / subtract prompts, a reference image, any --sim, --sharp, --enforce, --expand, --noise and
+--aest (with --aest-weights: the LAION linear head cannot be downloaded here) -- runs through the fused HIP engine
+(aphantasia_amd/engine.py).  --sync (LPIPS: a separate VGG network) is not part of this path.
 """
 import argparse
 import os
@@ -76,6 +76,9 @@ def get_args(argv=None):
     parser.add_argument(       '--clip-weights2', dest='clip_weights2', default=None, help='checkpoint of the --dualmod model (ViT-B-16.pt)')
     parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
     parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
+    parser.add_argument(       '--aest-weights', dest='aest_weights', default=None, help="state dict of the LAION aesthetic head (sa_0_4_vit_b_32_linear.pth: "
+                               "{'weight': [1,512], 'bias': [1]}); upstream downloads it (utils.py:402-413), there is no network here")
+    parser.add_argument(       '--aest-weights2', dest='aest_weights2', default=None, help='the head of the --dualmod model (sa_0_4_vit_b_16_linear.pth)')
     parser.add_argument(       '--rng',     default=None, choices=['bulk', 'reference'], help="host random draws: 'reference' = the reference's exact draw "
                                "order on torch's / numpy's global generators (a seeded run reproduces the reference's crop and augment tables); "
                                "'bulk' = vectorised draws from a numpy Generator (same distributions, a different stream, ~10x less host time). "
@@ -172,8 +175,34 @@ class FrameWriter:
         for t in self.ts: t.join()
 
 
+def _spawn_rank(local_rank, argv, world, port, run_id):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), APH_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    main(argv)
+
+
 def main(argv=None):
     a = get_args(argv)
+    # ---- multi-GPU (the reference is single-GPU): the cuts are split over the ranks of one node, one process
+    # per GPU, ONE RCCL all-reduce of the parameter gradient per step (aph_allreduce_f32).  Either launched by torchrun (RANK /
+    # WORLD_SIZE / LOCAL_RANK in the environment) or spawned from here with --ranks N.
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if a.ranks > 1 and 'RANK' not in os.environ:
+        import torch.multiprocessing as mp
+        if a.seed is None:
+            argv = list(sys.argv[1:] if argv is None else argv) + ['--seed', str(int.from_bytes(os.urandom(3), 'little'))]    # every rank must draw the same crop tables
+        port = 20000 + int.from_bytes(os.urandom(2), 'little') % 20000
+        mp.spawn(_spawn_rank, args=(list(sys.argv[1:] if argv is None else argv), a.ranks, port, 'r%d' % os.getpid()), nprocs=a.ranks, join=True)
+        return
+    comm = None
+    if world > 1:
+        if a.seed is None:
+            raise SystemExit(' multi-rank runs need --seed (every rank draws the same crop / augment tables and takes its share of the cuts)')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+        from aphantasia_amd import comm as acomm
+        comm = acomm.create(rank, world)
+        if rank != 0:
+            a.verbose, a.no_save, a.save_pt = False, True, False          # rank 0 reports and writes the frames
     if a.seed is not None:
         torch.manual_seed(a.seed)
         np.random.seed(a.seed)
@@ -261,9 +290,19 @@ def main(argv=None):
     tempdir = os.path.join(a.out_dir, out_name)
     os.makedirs(tempdir, exist_ok=True)
 
-    if a.aest != 0 or a.sync != 0:
-        raise SystemExit(' --aest (needs the aesthetic head weights) and --sync (LPIPS) are not part of the fused MI355X step; '
-                         'the drop-in autograd API (aphantasia_amd.utils / .clip) composes with torch ops for them')
+    if a.sync != 0:
+        raise SystemExit(' --sync (LPIPS: a separate VGG network, clip_fft.py:268-270) is not part of the MI355X path')
+
+    def load_aest(path):                                                              # utils.py:402-413 aesthetic_model()
+        if a.aest == 0:
+            return None
+        if path is None or not os.path.isfile(path):
+            raise SystemExit(' --aest needs the LAION linear head: pass its state dict with --aest-weights (upstream downloads '
+                             'sa_0_4_<model>_linear.pth from github.com/LAION-AI/aesthetic-predictor; there is no network here)')
+        sd = torch.load(path, map_location='cpu')
+        return (sd['weight'].float(), float(sd['bias'].reshape(-1)[0]), a.aest)
+    aest1 = load_aest(a.aest_weights)
+    aest2 = load_aest(a.aest_weights2) if a.dualmod is not None else None
     h, w = a.size
     if a.dwt is True:
         pk = dict(param_kind='dwt', dwt=image_f.synth)
@@ -272,12 +311,14 @@ def main(argv=None):
         pk = dict(param_kind='fft')
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
+                 optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
+                 rank=rank, world=world, comm=comm, aest=aest1, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
-                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
+                      optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
+                      rank=rank, world=world, comm=comm, aest=aest2, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp
@@ -296,8 +337,10 @@ def main(argv=None):
         if i % a.opt_step == 0 and writer is not None:
             img = e.synthesize(a.contrast)                                              # clip_fft.py:298-299
             writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)
-        if a.verbose and (i % 10 == 9 or i == a.steps - 1):
-            print(' step %d/%d  loss %.4f  %.1f steps/s' % (i + 1, a.steps, e.global_loss(), (i + 1) / (time.time() - t0)), flush=True)
+        if (a.verbose or world > 1) and (i % 10 == 9 or i == a.steps - 1):
+            gl = e.global_loss()               # (a collective when world > 1: every rank takes part, rank 0 prints)
+            if a.verbose:
+                print(' step %d/%d  loss %.4f  %.1f steps/s' % (i + 1, a.steps, gl, (i + 1) / (time.time() - t0)), flush=True)
     torch.cuda.synchronize()
     if writer is not None:
         writer.close()
@@ -308,7 +351,8 @@ def main(argv=None):
             shutil.copy(frames[-1], os.path.join(a.out_dir, '%s-%d.jpg' % (out_name, a.steps)))
     if a.save_pt is True:
         torch.save([p.detach().cpu() for p in params], '%s.pt' % os.path.join(a.out_dir, out_name))   # clip_fft.py:315 (list of tensors)
-    print(' done: %d steps in %.1fs (%.1f steps/s)' % (a.steps, time.time() - t0, a.steps / (time.time() - t0)))
+    if rank == 0:
+        print(' done: %d steps in %.1fs (%.1f steps/s)%s' % (a.steps, time.time() - t0, a.steps / (time.time() - t0), ' on %d ranks' % world if world > 1 else ''))
 
 
 if __name__ == '__main__':

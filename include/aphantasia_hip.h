@@ -165,6 +165,13 @@ int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const
                  int T, int n_broadcast, int s_total, int s_offset, int type, float denom, float gscale, float* d_ws,
                  float* d_loss, float* d_genc, void* stream);
 
+/* the aesthetic predictor term, clip_fft.py:255-256 / utils.py:402-413 (`loss -= 0.001 * a.aest * aest(out_enc).mean()`,
+ * aest = nn.Linear(D, 1)): adds coef * mean_s(w . enc_s + bias) to *d_loss and its gradient (times gscale) into d_genc
+ * (nullable), both ACCUMULATED on top of what aph_sim_loss wrote; denom as there.  d_w [D] device, bias a host scalar;
+ * pass coef = -0.001 * aest. */
+int aph_linear_head(const float* d_enc, int S, int D, const float* d_w, float bias, float coef, float denom, float gscale,
+                    float* d_loss, float* d_genc, void* stream);
+
 /* ---- optimiser: torch.optim.Adam / AdamW as configured at clip_fft.py:108-115 --------------- */
 /* d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale};
  * d_m may be NULL when beta1 == 0, d_vmax NULL unless amsgrad; decoupled_wd = AdamW */

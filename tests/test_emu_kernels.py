@@ -69,6 +69,10 @@ def test_sim_loss(emu, golden):
     K.check_sim_loss_per_cut(emu, 'cpu')
 
 
+def test_linear_head(emu):
+    K.check_linear_head(emu, 'cpu')
+
+
 def test_adam(emu):
     K.check_adam(emu, 'cpu')
 

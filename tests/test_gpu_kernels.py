@@ -73,6 +73,10 @@ def test_sim_loss(golden):
     K.check_sim_loss_per_cut(None, DEV)
 
 
+def test_linear_head():
+    K.check_linear_head(None, DEV)
+
+
 def test_adam():
     K.check_adam(None, DEV)
     K.check_adam(None, DEV, n=2769120)

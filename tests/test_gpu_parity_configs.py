@@ -277,6 +277,28 @@ def test_sharp_expand_terms_vs_oracle(b32):
     assert d.mean().item() < 1e-3, d.mean().item()
 
 
+def test_aesthetic_head_term_vs_oracle(b32):
+    """--aest (clip_fft.py:255-256, utils.py:402-413): `loss -= 0.001 * aest * Linear(512, 1)(out_enc).mean()` in the fused engine
+    (aph_linear_head) vs the oracle; a head with large weights so the term is a visible part of loss and gradient"""
+    h, w, S, aest = 256, 320, 6, 40.0
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    g = torch.Generator().manual_seed(7)
+    head_w, head_b = torch.randn(1, 512, generator=g), torch.randn(1, generator=g)
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), rng='reference', aest=(head_w, float(head_b), aest))
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, aest=(head_w, head_b, aest))
+    plain = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0)
+    for i in range(2):
+        seed_all(30 + i)
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        got, want = float(eng.step(table)), run.step(table)
+        if i == 0:
+            assert abs(want - plain.step(table)) > 0.01            # the head's term is not negligible in this test
+        assert abs(got - want) < 3e-4, (i, got, want)
+    compare_grad(eng.grad, run.params.grad, 0.999, 5e-2)
+
+
 @pytest.mark.parametrize('tf', ['none', 'fast'])
 def test_enforce_term_vs_oracle(b32, tf):
     """--enforce (clip_fft.py:271-275): a second independently drawn slice_imgs, pairwise similarity with gradient into both
@@ -340,44 +362,41 @@ def test_illustrip_rgb_step_vs_oracle(b32, fix):
 
 @pytest.mark.parametrize('gen', ['RGB', 'FFT'])
 def test_illustrip_frame_loop_vs_oracle(b32, gen):
-    """illustrip.py:381-423: per frame warp the current image (frame_transform; FFT mode: irfftn -> warp -> rfftn), re-create
-    the parameters from it and restart the optimiser -- engine (aph_frame_affine, aph_irfft2 / aph_rfft2, reset_params) vs the
-    oracle's loop (restated T.functional.affine, torch.fft, a fresh torch.optim.Adam per frame)"""
-    from aphantasia_amd import ops
+    """illustrip.py:367-470 through aphantasia_amd.illustrip_loop.FrameLoop: per frame warp the current picture
+    (frame_transform; FFT mode: irfftn -> warp -> rfftn), re-create the parameters from it, restart the optimiser, take
+    opt_step steps -- engine (aph_frame_affine, aph_irfft2 / aph_rfft2, reset_params, fused step) vs the oracle's loop
+    (restated T.functional.affine, torch.fft, a fresh ReferenceRun / torch.optim.Adam per frame)"""
+    from aphantasia_amd.illustrip_loop import FrameLoop
     h, w, S = 256, 320, 6
     tgt = target512()
-    motion = (2.0, (3, -1), 1.03, 1.0)             # angle, shift, scale, shear
+    motion = dict(angle=2.0, shift=(3, -1), scale=1.03, shear=1.0)
     seed_all(0)
     p0 = torch.randn(1, 3, h, w) * 0.3 if gen == 'RGB' else 0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)
-    kw = dict(sim='mix', transform=transforms.normalize(), rng='reference')
-    okw = dict(sim='mix')
+    kw = dict(sim='mix', transform=transforms.normalize(), rng='reference', lr=0.1)
+    okw = dict(sim='mix', lr=0.1)
     if gen == 'RGB':
         kw.update(param_kind='pixel', rgb_priors=True)
         okw.update(param_kind='pixel', rgb_priors=True)
     eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], **kw)
+    loop = FrameLoop(eng, gen=gen, opt_step=1)
     cur = p0
-    for frame in range(3):
-        run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=cur, **okw)       # new params + new optimiser every frame (illustrip.py:390,411-418)
-        for i in range(3):
-            seed_all(100 * frame + i)
-            table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
-            got, want = float(eng.step(table)), run.step(table)
-            assert abs(got - want) < 5e-4, (gen, frame, i, got, want)
-        # oracle-side re-parameterisation
-        prm = run.params.detach()
+    for frame in range(5):              # (past the third step the engine replays its hipGraph across the re-parameterisations)
+        # oracle: MOTION, new parameters, new optimiser (illustrip.py:381-418), one step
         if gen == 'RGB':
-            cur = augment_ref.affine(prm, *motion)
-            new = transforms.frame_transform(eng.params.detach(), (h, w), *motion)
+            cur = augment_ref.affine(cur, motion['angle'], motion['shift'], motion['scale'], motion['shear'])
         else:
-            img = torch.fft.irfftn(torch.view_as_complex(prm.contiguous()), s=(h, w), norm='ortho')            # illustrip.py:401-403
-            img = augment_ref.affine(img, *motion)
-            cur = torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho')).contiguous()   # :407-408
-            plan = eng.plan
-            dimg = ops.irfft2(plan, eng.params.detach())
-            dimg = transforms.frame_transform(dimg.reshape(1, 3, h, w), (h, w), *motion)
-            new = ops.rfft2(plan, dimg.reshape(3, h, w).contiguous()).reshape(1, 3, h, w // 2 + 1, 2)
+            img = torch.fft.irfftn(torch.view_as_complex(cur.contiguous()), s=(h, w), norm='ortho')                          # illustrip.py:401-403
+            img = augment_ref.affine(img, motion['angle'], motion['shift'], motion['scale'], motion['shear'])
+            cur = torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho')).contiguous()                  # :407-408
+        run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=cur, **okw)
+        seed_all(100 + frame)
+        want = run.step(R.draw_crop_table(S, 224, h, w, 'uniform', 0.4))
+        seed_all(100 + frame)
+        loop.frame(**motion)
+        got = float(eng.loss)
+        assert abs(got - want) < 5e-4, (gen, frame, got, want)
+        new, cur = eng.params.detach().cpu().reshape(cur.shape), run.params.detach()
         scale = cur.abs().max().item()
-        assert (new.cpu() - cur).abs().max().item() < 2e-2 * scale, (gen, frame)
-        assert (new.cpu() - cur).abs().mean().item() < 2e-3 * scale, (gen, frame)
-        eng.reset_params(new)
-        assert eng.step_count == 0
+        # Adam with a fresh state moves every coordinate by ~lr * sign(g): a coordinate whose tiny gradient differs in sign is 2 lr off
+        assert (new - cur).abs().mean().item() < 2e-3 * max(scale, 1.0), (gen, frame, (new - cur).abs().mean().item())
+        assert eng.step_count == 1
