@@ -271,8 +271,8 @@ def check_linear_head(lib, dev):
     loss = torch.full((1,), 0.5).to(dev)
     genc0 = torch.randn(S, Dm, generator=g)
     genc = genc0.clone().to(dev)
-    L.call('aph_linear_head', ops.ptr(enc.detach().to(dev).contiguous()), S, Dm, ops.ptr(w.reshape(-1).to(dev).contiguous()), b, -0.001 * 25.0, float(S), 8.0,
-           ops.ptr(loss), ops.ptr(genc), ops._stream(loss))
+    d_enc, d_w = enc.detach().to(dev).contiguous(), w.reshape(-1).to(dev).contiguous()        # (held: ops.ptr() keeps no reference)
+    L.call('aph_linear_head', ops.ptr(d_enc), S, Dm, ops.ptr(d_w), b, -0.001 * 25.0, float(S), 8.0, ops.ptr(loss), ops.ptr(genc), ops._stream(loss))
     assert abs(loss.item() - 0.5 - want.item()) < 1e-6
     assert np.allclose((genc.cpu() - genc0).numpy() / 8.0, enc.grad.numpy(), rtol=1e-4, atol=2e-7)      # (difference of O(1) f32 values)
 
