@@ -163,13 +163,9 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
   }
 }
 
-// `only_persp` (with an augment table): just the cuts that drew a perspective -- the others are produced by
-// crop_warp_fused_kernel without the scratch round trip
 template <int OUT>
-__global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g,
-                                   const float* __restrict__ only_persp) {
+__global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g) {
   const int s = blockIdx.z;
-  if (only_persp && only_persp[(size_t)s * APH_AUG_STRIDE + 8] == 0.f) return;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);      // (no integer division per pixel)
   if (i >= g.size || j >= g.size) return;
   const CutBox b = load_cut(table, s, g.size);
@@ -432,17 +428,19 @@ __device__ __forceinline__ bool in_rect(const float* __restrict__ a, int y, int 
 // sampled value times sampled ones-mask (fill = 0); ERASE: source pixels inside the erase rectangle read as 0
 template <bool ERASE>
 __device__ __forceinline__ float warp_gather(const float* __restrict__ src, const Tap& t, int n, const float* __restrict__ a) {
+  // branch-free: out-of-range taps read a clamped address with weight 0, so the four loads issue together
   float v = 0.f, m = 0.f;
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx) {
       const int yy = t.y0 + dy, xx = t.x0 + dx;
-      if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
-      const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
+      const bool in = yy >= 0 && yy < n && xx >= 0 && xx < n;
+      const float w = in ? (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0) : 0.f;
+      const int yc = yy < 0 ? 0 : (yy > n - 1 ? n - 1 : yy), xc = xx < 0 ? 0 : (xx > n - 1 ? n - 1 : xx);
+      const float sv = src[(size_t)yc * n + xc];
       m += w;
-      if (ERASE && in_rect(a, yy, xx)) continue;
-      v += w * src[(size_t)yy * n + xx];
+      v += (ERASE && in_rect(a, yc, xc)) ? 0.f : w * sv;
     }
   return v * m;
 }
@@ -465,10 +463,9 @@ __global__ void persp_kernel(const float* __restrict__ A, const float* __restric
 // stage 2: RandomErasing (read-side) + rotation + normalise + emit
 template <int OUT>
 __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __restrict__ Bi, const float* __restrict__ aug,
-                                   void* __restrict__ out, int n, int patch, int only_persp) {
+                                   void* __restrict__ out, int n, int patch) {
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
-  if (only_persp && a[8] == 0.f) return;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= n || j >= n) return;
   const int pix = i * n + j;
@@ -482,127 +479,6 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
     float v[3];
     for (int c = 0; c < 3; ++c) v[c] = in_rect(a, i, j) ? 0.f : src[((size_t)s * 3 + c) * n * n + pix];
     emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
-  }
-}
-
-// Cuts WITHOUT a perspective (80 % of them under transforms_fast): bicubic resize -> RandomErasing -> rotation -> normalise
-// -> emit in ONE kernel.  The stages stay sequential (transforms.py:165-170: every rotated pixel is a bilinear blend of four
-// pixels of the resized, erased cut) -- the intermediate cut simply lives in LDS instead of HBM: a workgroup owns a 32x32
-// output tile, builds the part of the resized cut its rotated footprint touches (<= 32 sqrt(2) + taps per side) and samples
-// it.  Replaces a 114 MB f32 scratch write + gather read per step at the headline size.
-constexpr int kFT = 32;        // output tile side
-constexpr int kFMAX = 52;      // footprint side bound: 32 * sqrt(2) = 45.3, + 2 taps, + rounding margin
-
-template <int OUT>
-__global__ __launch_bounds__(256) void crop_warp_fused_kernel(const float* __restrict__ rgb, const int* __restrict__ table,
-                                                              const float* __restrict__ aug, void* __restrict__ out, Geom g) {
-  __shared__ float fp[3][kFMAX][kFMAX + 1];
-  __shared__ __attribute__((aligned(16))) half_t stg[3 * kFT * kFT];
-  const int s = blockIdx.y;
-  const float* a = aug + (size_t)s * APH_AUG_STRIDE;
-  if (a[8] != 0.f) return;                      // perspective cuts: scratch path
-  const int n = g.size, tiles = (n + kFT - 1) / kFT;
-  const int tby = blockIdx.x / tiles, tbx = blockIdx.x - tby * tiles;
-  const int ti0 = tby * kFT, tj0 = tbx * kFT;
-  const int ti1 = (ti0 + kFT < n ? ti0 + kFT : n) - 1, tj1 = (tj0 + kFT < n ? tj0 + kFT : n) - 1;
-  const bool rot = a[15] != 0.f;
-  const float rc = a[13], rs = a[14];
-  const CutBox b = load_cut(table, s, n);
-  int x0 = tj0, x1 = tj1, y0 = ti0, y1 = ti1;
-  if (rot) {
-    // the map is affine, floor is monotone: the extreme taps of the tile are those of its corners (+-1 for fp rounding)
-    int xa = 1 << 30, xb = -(1 << 30), ya = 1 << 30, yb = -(1 << 30);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const Tap t = rot_tap(rc, rs, (k & 2) ? ti1 : ti0, (k & 1) ? tj1 : tj0, n);
-      xa = t.x0 < xa ? t.x0 : xa; xb = t.x0 > xb ? t.x0 : xb;
-      ya = t.y0 < ya ? t.y0 : ya; yb = t.y0 > yb ? t.y0 : yb;
-    }
-    x0 = xa - 1; x1 = xb + 2; y0 = ya - 1; y1 = yb + 2;
-    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > n - 1 ? n - 1 : x1; y1 = y1 > n - 1 ? n - 1 : y1;
-  }
-  const int FW = x1 - x0 + 1, FH = y1 - y0 + 1;
-  const bool staged = FW >= 1 && FH >= 1 && FW <= kFMAX && FH <= kFMAX;      // always, for a rotation; else: taps straight from the image
-  if (staged) {
-    const float c = 0.5f * (float)(n - 1), rfw = 1.0f / (float)FW;
-    for (int idx = threadIdx.x; idx < FH * FW; idx += blockDim.x) {
-      const int fy = (int)(((float)idx + 0.5f) * rfw), fx = idx - fy * FW, y = y0 + fy, x = x0 + fx;      // exact for idx < 52 * 52
-      if (rot) {
-        // only pixels within two pixels of the tile's pre-image can be tapped: skip the corners of the bounding box
-        const float ux = (float)x - c, uy = (float)y - c;
-        const float qx = rc * ux - rs * uy + c, qy = rs * ux + rc * uy + c;
-        if (qx < (float)tj0 - 2.5f || qx > (float)tj1 + 2.5f || qy < (float)ti0 - 2.5f || qy > (float)ti1 + 2.5f) continue;
-      }
-      float v[3] = {0.f, 0.f, 0.f};
-      if (!in_rect(a, y, x)) bicubic3(rgb, g, b, y, x, v);                    // RandomErasing: value 0 inside the rectangle
-      fp[0][fy][fx] = v[0]; fp[1][fy][fx] = v[1]; fp[2][fy][fx] = v[2];
-    }
-  }
-  __syncthreads();
-  // patch-major f16 output of a full tile: stage in output order, then 16-byte stores (whole lines instead of 2-byte scatters)
-  const int p = g.patch;
-  const bool pack = OUT == APH_OUT_PATCH_F16 && p >= 4 && p <= kFT && ti1 - ti0 == kFT - 1 && tj1 - tj0 == kFT - 1 && (ti0 % p) == 0;
-  const int lp = pack ? __ffs(p) - 1 : 0;
-  for (int pix = threadIdx.x; pix < kFT * kFT; pix += blockDim.x) {
-    const int li = pix / kFT, lj = pix - li * kFT, i = ti0 + li, j = tj0 + lj;
-    if (i > ti1 || j > tj1) continue;
-    float v[3];
-    if (!staged) {            // defensive path: no LDS image (footprint larger than the buffer)
-      if (rot) {
-        const Tap t = rot_tap(rc, rs, i, j, n);
-        float m = 0.f; v[0] = v[1] = v[2] = 0.f;
-        for (int dy = 0; dy < 2; ++dy)
-          for (int dx = 0; dx < 2; ++dx) {
-            const int yy = t.y0 + dy, xx = t.x0 + dx;
-            if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
-            const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
-            m += w;
-            if (in_rect(a, yy, xx)) continue;
-            float q[3];
-            bicubic3(rgb, g, b, yy, xx, q);
-            v[0] += w * q[0]; v[1] += w * q[1]; v[2] += w * q[2];
-          }
-        v[0] *= m; v[1] *= m; v[2] *= m;
-      } else {
-        v[0] = v[1] = v[2] = 0.f;
-        if (!in_rect(a, i, j)) bicubic3(rgb, g, b, i, j, v);
-      }
-    } else if (rot) {
-      const Tap t = rot_tap(rc, rs, i, j, n);
-      float m = 0.f; v[0] = v[1] = v[2] = 0.f;
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int yy = t.y0 + dy, xx = t.x0 + dx;
-          if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
-          const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
-          m += w;                                                               // sampled ones-mask (fill = 0)
-          v[0] += w * fp[0][yy - y0][xx - x0]; v[1] += w * fp[1][yy - y0][xx - x0]; v[2] += w * fp[2][yy - y0][xx - x0];
-        }
-      v[0] *= m; v[1] *= m; v[2] *= m;
-    } else {
-      v[0] = fp[0][li][lj]; v[1] = fp[1][li][lj]; v[2] = fp[2][li][lj];
-    }
-    if (pack) {
-      const int pl = ((li >> lp) * (kFT >> lp) + (lj >> lp)) * (3 << (2 * lp)) + ((li & (p - 1)) << lp) + (lj & (p - 1));
-      stg[pl] = (half_t)((v[0] - kClipMean[0]) / kClipStd[0]);
-      stg[pl + (1 << (2 * lp))] = (half_t)((v[1] - kClipMean[1]) / kClipStd[1]);
-      stg[pl + (2 << (2 * lp))] = (half_t)((v[2] - kClipMean[2]) / kClipStd[2]);
-    } else {
-      emit3<OUT>(out, s, i, j, n, p, v[0], v[1], v[2]);
-    }
-  }
-  if (pack) {
-    __syncthreads();
-    const int per = 3 << (2 * lp);                       // halfs per patch (a multiple of 8 for p >= 4)
-    half_t* o = reinterpret_cast<half_t*>(out);
-    for (int ch = threadIdx.x; ch < 3 * kFT * kFT / 8; ch += blockDim.x) {
-      const int e = ch * 8, lpatch = e / per, off = e - lpatch * per;
-      const int pi = lpatch / (kFT >> lp), pj = lpatch - pi * (kFT >> lp);
-      const size_t base = patch_index(s, 0, ti0 + (pi << lp), tj0 + (pj << lp), n, p);
-      *reinterpret_cast<half8*>(o + base + off) = *reinterpret_cast<const half8*>(stg + e);
-    }
   }
 }
 
@@ -641,17 +517,44 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
       const float qx = cs * ux - sn * uy + c, qy = sn * ux + cs * uy + c;
       const float rad = fabsf(cs) + fabsf(sn) + 0.02f;
       int j0 = (int)ceilf(qx - rad), j1 = (int)floorf(qx + rad), i0 = (int)ceilf(qy - rad), i1 = (int)floorf(qy + rad);
-      j0 = j0 < 0 ? 0 : j0; i0 = i0 < 0 ? 0 : i0; j1 = j1 > n - 1 ? n - 1 : j1; i1 = i1 > n - 1 ? n - 1 : i1;
-      for (int i = i0; i <= i1; ++i)
-        for (int j = j0; j <= j1; ++j) {
-          const Tap t = rot_tap(cs, sn, i, j, n);
-          const float w = tap_hits(t, py, px);
-          if (w == 0.f) continue;
-          const float wm = w * tap_mask(t, n);
-          float gq[3];
-          fetch_grad3<OUT>(gout, s, i, j, n, patch, gq);
-          g0 += wm * gq[0]; g1 += wm * gq[1]; g2 += wm * gq[2];
+      if (rad <= 1.45f) {
+        // a rotation: the candidates fit a 3 x 3 box.  Branch-free -- every candidate's footprint is re-derived with the forward's
+        // own arithmetic, a miss gets weight 0 and a clamped address, and the 27 gathers issue together (one memory round trip
+        // instead of one per candidate)
+        float wm[9];
+        size_t off[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+          const int i = i0 + d / 3, j = j0 + d % 3;
+          const bool ok = i >= 0 && i <= n - 1 && j >= 0 && j <= n - 1 && i <= i1 && j <= j1;
+          const int ic = i < 0 ? 0 : (i > n - 1 ? n - 1 : i), jc = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+          const Tap t = rot_tap(cs, sn, ic, jc, n);
+          const float w = ok ? tap_hits(t, py, px) : 0.f;
+          wm[d] = w * tap_mask(t, n);
+          off[d] = is_patch<OUT>::v ? patch_index(s, 0, ic, jc, n, patch) : ((size_t)s * 3 * n + ic) * n + jc;
         }
+        const size_t cstride = is_patch<OUT>::v ? (size_t)patch * patch : (size_t)n * n;
+        float gv[9][3];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+          gv[d][0] = gload<OUT>(gout, off[d]); gv[d][1] = gload<OUT>(gout, off[d] + cstride); gv[d][2] = gload<OUT>(gout, off[d] + 2 * cstride);
+        }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { g0 += wm[d] * gv[d][0]; g1 += wm[d] * gv[d][1]; g2 += wm[d] * gv[d][2]; }
+        if (OUT != APH_OUT_NCHW_RAW) { g0 /= kClipStd[0]; g1 /= kClipStd[1]; g2 /= kClipStd[2]; }
+      } else {
+        j0 = j0 < 0 ? 0 : j0; i0 = i0 < 0 ? 0 : i0; j1 = j1 > n - 1 ? n - 1 : j1; i1 = i1 > n - 1 ? n - 1 : i1;
+        for (int i = i0; i <= i1; ++i)
+          for (int j = j0; j <= j1; ++j) {
+            const Tap t = rot_tap(cs, sn, i, j, n);
+            const float w = tap_hits(t, py, px);
+            if (w == 0.f) continue;
+            const float wmm = w * tap_mask(t, n);
+            float gq[3];
+            fetch_grad3<OUT>(gout, s, i, j, n, patch, gq);
+            g0 += wmm * gq[0]; g1 += wmm * gq[1]; g2 += wmm * gq[2];
+          }
+      }
     } else {
       float gq[3];
       fetch_grad3<OUT>(gout, s, py, px, n, patch, gq);
@@ -817,26 +720,19 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   const int n = g.size;
   const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S), block(256);       // thread = (column, row) of a cut: 64 x 4 pixels per workgroup
   if (!aug) {
-    const float* none = nullptr;
-    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
-    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
-    else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g, none);
+    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g);
+    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, rgb, (const int*)table, out, g);
+    else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g);
     return aph_check_launch("aph_sample_fwd");
   }
   float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
   float* Bv = A + scratch_floats(g);
-  // cuts without a perspective: one fused kernel, no scratch
-  const int tiles = (n + kFT - 1) / kFT;
-  const dim3 fgrid(tiles * tiles, g.S);
-  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_NCHW_RAW>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
-  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_NCHW_NORM>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
-  else APH_LAUNCH(crop_warp_fused_kernel<APH_OUT_PATCH_F16>, fgrid, block, 0, st, rgb, (const int*)table, aug, out, g);
-  // cuts with a perspective (p = 0.2): resized cut -> A, perspective A -> B, erase + rotation B -> out (workgroups of the other cuts exit at once)
-  APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g, aug);
+  // resized cut -> A; RandomPerspective for the cuts that drew it A -> B; RandomErasing + rotation + normalise (A or B) -> out
+  APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g);
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
-  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
-  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
-  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch, 1);
+  if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
+  else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
+  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
   return aph_check_launch("aph_sample_fwd");
   APH_CATCH
 }

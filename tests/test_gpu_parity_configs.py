@@ -397,6 +397,7 @@ def test_illustrip_frame_loop_vs_oracle(b32, gen):
         loop.frame(**motion)
         got = float(eng.loss)
         assert abs(got - want) < 5e-4, (gen, frame, got, want)
+        assert int(eng.guard[0]) == 0, (gen, frame, 'fp16 overflow in the backward: step skipped', float(eng.grad.abs().max()))
         new, cur = eng.params.detach().cpu().reshape(cur.shape), run.params.detach()
         scale = cur.abs().max().item()
         # Adam with a fresh state moves every coordinate by ~lr * sign(g): a coordinate whose tiny gradient differs in sign is 2 lr off
