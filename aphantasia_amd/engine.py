@@ -389,13 +389,19 @@ class Engine:
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
-        if self.world > 1 and self.params.is_cuda:
-            # Multi-rank: run the step on a dedicated stream rather than the legacy default (NULL) stream, whose implicit
-            # synchronisation with other streams interacts with the collective backend's own streams.  The caller's
-            # stream is fenced on entry and exit, so results are visible to it as before.
+        if self.params.is_cuda:
+            # The step always runs on a stream of its own, never on the legacy default (NULL) stream: hipGraph replays launched on
+            # the NULL stream next to eager work and device-wide synchronizes were measured to corrupt the step on this runtime
+            # (ROCm 7.2 / gfx950: eager kernels -> hipDeviceSynchronize -> async H2D copies -> graph replay gave NaN gradients from
+            # the second replay on, every time; the same sequence on a non-NULL stream never did -- tools/exp/frame_debug3.py; the
+            # multi-rank variant of this was found in round 1).  The caller's stream is fenced on entry and on exit, so whatever it
+            # enqueued before (re-parameterisation, frame conversion) is complete before the step and the step's results are visible
+            # to it afterwards.
             if self._own_stream is None:
                 self._own_stream = torch.cuda.Stream(device=self.dev)
             cur = torch.cuda.current_stream(self.dev)
+            if cur == self._own_stream:
+                return self._step(table, augs, lr, shift, tables2)
             self._own_stream.wait_stream(cur)
             with torch.cuda.stream(self._own_stream):
                 out = self._step(table, augs, lr, shift, tables2)

@@ -235,6 +235,7 @@ def main():
     eng, eng_b = make(cfg['transform'], S)
     dt = timed(eng, eng_b, a.steps, a.warmup)
     loss = eng.global_loss()
+    skipped = int(eng.guard[0])          # steps whose fp16 backward overflowed and were skipped by the guarded Adam: must be 0 for a valid line
     flop_step = 2 * S * F_IMG[cfg['model']] / 1e12
     if dualmod is not None:     # the schedule's mix of B/32 and B/16 steps over the timed region
         n16 = len([i for i in range(a.steps) if i >= dualmod and i % dualmod == 0])
@@ -344,7 +345,7 @@ def main():
                                                                                     cfg['samples'], S, cfg['transform'], sim),
                        'note': cfg['note'], 'samples_effective': S,
                        'parallelism': 'samples split over %d rank(s), 1 all-reduce/step (%s)' % (world, 'none' if world == 1 else ('RCCL direct, aph_allreduce_f32' if comm is not None else 'torch.distributed ' + backend)),
-                       'loss_scale': LOSS_SCALE, 'final_loss': loss, 'algorithmic_tflop_per_step': flop_step,
+                       'loss_scale': LOSS_SCALE, 'final_loss': loss, 'skipped_steps': skipped, 'algorithmic_tflop_per_step': flop_step,
                        'lib_sha256': lib_sha()[:16]},
             'legs': legs, 'roofline': roof, 'cpu_baseline': cpu,
         }
