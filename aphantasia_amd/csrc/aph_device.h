@@ -175,4 +175,19 @@ __device__ __forceinline__ float dot2_f16(half2 a, half2 b, float c) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Zero-fill as a KERNEL (16 bytes per lane, grid-stride).  The step's launch sequence is captured into a hipGraph; with
+// hipMemsetAsync the graph held memset nodes, and replays of such a graph next to eager work on the legacy default stream
+// were measured to corrupt the backward pass on this runtime (tools/exp/frame_debug3.py).  A graph of kernel nodes only
+// does not.  n16 = number of 16-byte units (buffers here are 256-byte aligned and sized).
+static __global__ void zero16_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static __global__ void zero4_kernel(int* __restrict__ p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = 0; }
+static inline void zero_fill_async(void* p, size_t bytes, hipStream_t st) {       // bytes % 16 == 0
+  const size_t n16 = bytes / 16;
+  unsigned grid = (unsigned)((n16 + 255) / 256);
+  grid = grid > 2048u ? 2048u : (grid ? grid : 1u);
+  APH_LAUNCH(zero16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4*>(p), n16);
+}
+
 }  // namespace aph

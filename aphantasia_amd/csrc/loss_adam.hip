@@ -270,7 +270,7 @@ int aph_adam_step_guarded(float* d_p, const float* d_g, float* d_m, float* d_v, 
   APH_TRY
   if (!d_p || !d_g || !d_v || !d_hyper || !d_guard) return aph_fail(APH_ERR_ARG, "aph_adam_step_guarded: null argument");
   hipStream_t st = (hipStream_t)stream_;
-  APH_HIP(hipMemsetAsync(d_guard + 1, 0, sizeof(int), st));
+  APH_LAUNCH(zero4_kernel, dim3(1), dim3(64), 0, st, d_guard + 1);
   APH_LAUNCH(grad_guard_kernel, dim3(512), dim3(256), 0, st, d_g, n, d_guard);
   APH_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, st, d_p, d_g, d_m, d_v, d_vmax, d_hyper, decoupled_wd, n, d_guard);
   return aph_check_launch("aph_adam_step_guarded");

@@ -314,14 +314,14 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
   // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
-  APH_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)M * D, st));
+  zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];
     const bool cls_only = li + 1 == v->L;          // see aph_vit_forward: the last block's MLP / out-proj saw class rows only
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
-    if (cls_only) APH_HIP(hipMemsetAsync(v->datt, 0, sizeof(half_t) * (size_t)M * D, st));   // no gradient into the other rows' attention output
+    if (cls_only) zero_fill_async(v->datt, sizeof(half_t) * (size_t)M * D, st);   // no gradient into the other rows' attention output
     vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);

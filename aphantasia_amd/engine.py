@@ -74,10 +74,11 @@ class Engine:
                 raise NotImplementedError("sim 'dot' with --enforce / --expand is not supported in the fused engine "
                                           "(use the drop-in autograd API: aphantasia_amd.utils.sim_func composes it from torch ops)")
         self.rng_mode = rng
-        # hipGraph replay is a single-rank optimisation (it only saves host time; on the 128-core GPU box eager launches
-        # measure the same step time at every shard size).  Multi-rank runs launch eagerly: graph replays next to a
-        # collective backend's streams gave NaN / wrong gradients after the mid-run barrier + device synchronize that
-        # bench.py performs (reproduced with gloo on one device and with RCCL at world size 1; eager launches never did).
+        # hipGraph replay only saves host time (on the 128-core GPU box eager launches measure the same step time at every
+        # shard size).  Round 1 saw NaN gradients from replays next to eager work + device synchronizes; the cause turned out to
+        # be the graph's MEMSET nodes (captured hipMemsetAsync), which this runtime mis-orders -- the step now zero-fills with
+        # kernels (csrc/aph_device.h zero_fill_async; repro: tools/exp/frame_debug3.py on the commit before).  Multi-rank runs
+        # still launch eagerly by default because a graph with an RCCL node could only be exercised at world size 1 here.
         if world > 1 and not (comm is not None and os.environ.get('APH_MULTIRANK_GRAPH') == '1'):
             use_graph = False          # APH_MULTIRANK_GRAPH=1: the whole step INCLUDING the RCCL all-reduce and Adam as one graph
         self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
@@ -141,7 +142,6 @@ class Engine:
         self.ws = torch.empty(Sl * (len(self.coef) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.dev)      # [skipped-step count, scratch]
-        self._own_stream = None
         self._stage, self._stage_i = None, 0       # pinned host ring for the per-step H2D refreshes (built lazily, GPU only)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
         self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
@@ -389,24 +389,6 @@ class Engine:
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
-        if self.params.is_cuda:
-            # The step always runs on a stream of its own, never on the legacy default (NULL) stream: hipGraph replays launched on
-            # the NULL stream next to eager work and device-wide synchronizes were measured to corrupt the step on this runtime
-            # (ROCm 7.2 / gfx950: eager kernels -> hipDeviceSynchronize -> async H2D copies -> graph replay gave NaN gradients from
-            # the second replay on, every time; the same sequence on a non-NULL stream never did -- tools/exp/frame_debug3.py; the
-            # multi-rank variant of this was found in round 1).  The caller's stream is fenced on entry and on exit, so whatever it
-            # enqueued before (re-parameterisation, frame conversion) is complete before the step and the step's results are visible
-            # to it afterwards.
-            if self._own_stream is None:
-                self._own_stream = torch.cuda.Stream(device=self.dev)
-            cur = torch.cuda.current_stream(self.dev)
-            if cur == self._own_stream:
-                return self._step(table, augs, lr, shift, tables2)
-            self._own_stream.wait_stream(cur)
-            with torch.cuda.stream(self._own_stream):
-                out = self._step(table, augs, lr, shift, tables2)
-            cur.wait_stream(self._own_stream)
-            return out
         return self._step(table, augs, lr, shift, tables2)
 
     def _step(self, table, augs, lr, shift, tables2):

@@ -1,8 +1,10 @@
-"""Repro of the runtime defect behind Engine.step()'s dedicated stream: on the legacy default (NULL) stream the sequence
-   eager kernels -> device synchronize -> async H2D copies -> hipGraph replay
-gives NaN gradients from the second replay on (the guarded Adam skips those steps: `guard` counts them); the same sequence on
-a non-NULL stream is clean.  Engine._step is called directly here to stay on the caller's stream (Engine.step() itself always
-switches to its own stream)."""
+"""Repro harness for the hipGraph memset-node defect (ROCm 7.2 / gfx950): a captured step that contained hipMemsetAsync nodes,
+replayed in the sequence
+   eager kernels -> device synchronize -> async H2D copies -> graph replay
+produced NaN gradients from the second replay on (the guarded Adam skipped those steps: `guard` counts them), on the NULL
+stream and on a dedicated stream alike when the eager kernels ran on the NULL stream.  With the memsets replaced by fill
+kernels (csrc/aph_device.h zero_fill_async) both variants below print all zeros; check out the commit before that change to
+see the counters climb from frame 3."""
 import sys, os, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -22,17 +24,14 @@ def run(own_stream):
     eng = Engine(p0.cuda().contiguous(), h, w, model, S, [(tgt, -1.0)], sim='mix', transform=transforms.normalize(), rng='reference', lr=0.1,
                  use_graph=True, param_kind='pixel', rgb_priors=True)
     loop = FrameLoop(eng, gen='RGB', opt_step=1)
-    if not own_stream:
-        def on_callers_stream(table=None, augs=None, lr=None, shift=None, tables2=None):
-            torch.cuda.synchronize()
-            return eng._step(table, augs, lr, shift, tables2)
-        eng.step = on_callers_stream
-    else:
-        orig = eng.step
-        def synced(*a, **k):
-            torch.cuda.synchronize()
-            return orig(*a, **k)
-        eng.step = synced
+    orig = eng.step
+    def synced(*a, **k):
+        torch.cuda.synchronize()
+        if own_stream:
+            with torch.cuda.stream(STREAM):
+                return orig(*a, **k)
+        return orig(*a, **k)
+    eng.step = synced
     skipped = []
     for frame in range(8):
         torch.manual_seed(100 + frame); np.random.seed(100 + frame)
@@ -41,5 +40,6 @@ def run(own_stream):
     return skipped
 
 
-print('step on the NULL stream (Engine._step)      skipped-step counter per frame', run(False))
-print('step on the engine stream (Engine.step)     skipped-step counter per frame', run(True))
+STREAM = torch.cuda.Stream()
+print('step on the NULL stream       skipped-step counter per frame', run(False))
+print('step on a dedicated stream    skipped-step counter per frame', run(True))
