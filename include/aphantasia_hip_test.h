@@ -25,8 +25,9 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
                     void* stream);
 
-/* MFMA shape of the GEMM main loops launched from now on (process-wide): 1 = v_mfma_f32_32x32x16_f16 (default),
- * 0 = v_mfma_f32_16x16x32_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
+/* MFMA shape of the GEMM main loops launched from now on (process-wide): 0 = v_mfma_f32_16x16x32_f16 (default: measured
+ * faster on MI355X with real operands -- the chip is power-limited there and the 32x32x16 form sustains less),
+ * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
 int aph_gemm_set_mfma32(int on);
 
 #ifdef __cplusplus
