@@ -44,7 +44,7 @@ def main():
         w = csv.writer(f)
         w.writerow(['kernel', 'launches', 'launches_per_step', 'fetch_MB_per_launch(2xFETCH_SIZE)', 'write_MB_per_launch', 'total_MB_per_launch'])
         w.writerows(rows)
-    gem = [r for r in rows if 'gemm' in r[0] and r[2] >= 1 and 'splitk' not in r[0].lower()]
+    gem = [r for r in rows if 'gemm' in r[0] and r[2] >= 1 and 'splitk_reduce' not in r[0]]      # (the ring kernels' signatures contain 'SplitK')
     gl = sum(r[1] for r in gem)
     lib = os.path.join(ROOT, 'aphantasia_amd', 'libaphantasia_hip.so')
     out = dict(kernel_family='aph::gemm*_f16_kernel (launches occurring every step)', launches=gl,
