@@ -163,15 +163,52 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
   }
 }
 
+// XCD-aware forward (speed only; any assignment is correct).  The image (11 MB at 720p) does not fit one XCD's 4 MB L2, and with
+// the plain (x, y, cut) grid every XCD gathers from all of it: 487 MB of fabric fetch per launch for 11 MB of source.  Here the
+// unit of work is (cut, group of 4 output rows); strip_list_kernel assigns every unit to the XCD that owns the 32-pixel image
+// strip its source rows fall into (strips interleaved over the XCDs: strip t -> XCD t % 8, so every XCD sees centre and edge
+// strips alike), and crop_resize_strips_kernel's workgroup b, which runs on XCD b % 8 (observed dispatch order), walks that
+// XCD's list.  An XCD then touches ~1.4 / 8 of the image.
+constexpr int kStripPx = 32;
+constexpr int kStripSlots = 768;          // workgroups per XCD in crop_resize_strips_kernel
+
+// lists: [8][cap] unit ids (cut * groups + row group), counts: [8]; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void strip_list_kernel(const int* __restrict__ table, int* __restrict__ lists, int* __restrict__ counts, int cap, Geom g) {
+  __shared__ int cnt[8];
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int groups = (g.size + 3) / 4, units = g.S * groups;
+  for (int u = threadIdx.x; u < units; u += blockDim.x) {
+    const int s = u / groups, rg = u - s * groups;
+    const CutBox b = load_cut(table, s, g.size);
+    int i = rg * 4 + 2; i = i > g.size - 1 ? g.size - 1 : i;
+    int yy = (int)floorf(b.scale * (float)i); yy = yy > b.cs - 1 ? b.cs - 1 : yy;
+    const int yc = wrap(b.oy + yy - g.py0, g.H);
+    const int xcd = (yc / kStripPx) & 7;
+    const int pos = atomicAdd(&cnt[xcd], 1);            // (order inside a list is irrelevant: units are independent)
+    lists[xcd * cap + pos] = u;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) counts[threadIdx.x] = cnt[threadIdx.x];
+}
+
 template <int OUT>
-__global__ void crop_resize_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g) {
-  const int s = blockIdx.z;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);      // (no integer division per pixel)
-  if (i >= g.size || j >= g.size) return;
-  const CutBox b = load_cut(table, s, g.size);
-  float v[3];
-  bicubic3(rgb, g, b, i, j, v);
-  emit3<OUT>(out, s, i, j, g.size, g.patch, v[0], v[1], v[2]);
+__global__ __launch_bounds__(256) void crop_resize_strips_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g,
+                                                                 const int* __restrict__ lists, const int* __restrict__ counts, int cap) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int count = counts[xcd], groups = (g.size + 3) / 4, n = g.size;
+  for (int it = slot; it < count; it += nslot) {
+    const int u = lists[xcd * cap + it];
+    const int s = u / groups, rg = u - s * groups;
+    const CutBox b = load_cut(table, s, n);
+    for (int p = threadIdx.x; p < 4 * n; p += blockDim.x) {
+      const int di = p / n, j = p - di * n, i = rg * 4 + di;
+      if (i >= n) continue;
+      float v[3];
+      bicubic3(rgb, g, b, i, j, v);
+      emit3<OUT>(out, s, i, j, n, g.patch, v[0], v[1], v[2]);
+    }
+  }
 }
 
 // Adjoint of crop_resize over all cuts -- deterministic gather, one 16x16 pixel tile per workgroup.
@@ -700,6 +737,18 @@ size_t tab_bytes(const Geom& g) {
   return ((size_t)g.S * 2 * maxcs * sizeof(AdjEntry) + 255) & ~(size_t)255;
 }
 size_t scratch_floats(const Geom& g) { return (size_t)g.S * 3 * g.size * g.size; }
+// per-XCD unit lists of the forward: [8][cap] + [8] ints
+int strip_cap(const Geom& g) { return g.S * ((g.size + 3) / 4); }
+size_t strip_bytes(const Geom& g) { return ((size_t)(8 * (size_t)strip_cap(g) + 8) * sizeof(int) + 255) & ~(size_t)255; }
+
+template <int OUT>
+void launch_crop_resize(const float* rgb, const int* table, void* out, const Geom& g, void* ws, hipStream_t st) {
+  // ws: [tap tables | strip lists | ...]
+  int* lists = reinterpret_cast<int*>(static_cast<char*>(ws) + tab_bytes(g));
+  int* counts = lists + 8 * (size_t)strip_cap(g);
+  APH_LAUNCH(strip_list_kernel, dim3(1), dim3(1024), 0, st, table, lists, counts, strip_cap(g), g);
+  APH_LAUNCH(crop_resize_strips_kernel<OUT>, dim3(8 * kStripSlots), dim3(256), 0, st, rgb, table, out, g, (const int*)lists, (const int*)counts, strip_cap(g));
+}
 
 template <int OUT>
 int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, AdjEntry* tab, hipStream_t st) {
@@ -716,28 +765,28 @@ extern "C" {
 size_t aph_sample_ws_bytes(const aph_sample_geom* gg, int with_aug) {
   if (!gg || gg->S < 1 || gg->size < 1 || gg->Hp < 1 || gg->Wp < 1) return 0;
   const Geom g = to_geom(gg);
-  return tab_bytes(g) + (with_aug ? 2 * scratch_floats(g) * sizeof(float) : 0);
+  return tab_bytes(g) + strip_bytes(g) + (with_aug ? 2 * scratch_floats(g) * sizeof(float) : 0);
 }
 
 int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* table, const float* aug, void* ws,
                    void* out, int out_mode, void* stream_) {
   APH_TRY
   if (int e = check_geom(gg, out_mode, "aph_sample_fwd")) return e;
-  if (!rgb || !table || !out || (aug && !ws)) return aph_fail(APH_ERR_ARG, "aph_sample_fwd: null argument");
+  if (!rgb || !table || !out || !ws) return aph_fail(APH_ERR_ARG, "aph_sample_fwd: null argument (the workspace of aph_sample_ws_bytes is required)");
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
   const int n = g.size;
   const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S), block(256);       // thread = (column, row) of a cut: 64 x 4 pixels per workgroup
   if (!aug) {
-    if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, out, g);
-    else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, rgb, (const int*)table, out, g);
-    else APH_LAUNCH(crop_resize_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, rgb, (const int*)table, out, g);
+    if (out_mode == APH_OUT_NCHW_RAW) launch_crop_resize<APH_OUT_NCHW_RAW>(rgb, (const int*)table, out, g, ws, st);
+    else if (out_mode == APH_OUT_NCHW_NORM) launch_crop_resize<APH_OUT_NCHW_NORM>(rgb, (const int*)table, out, g, ws, st);
+    else launch_crop_resize<APH_OUT_PATCH_F16>(rgb, (const int*)table, out, g, ws, st);
     return aph_check_launch("aph_sample_fwd");
   }
-  float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
+  float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g) + strip_bytes(g));
   float* Bv = A + scratch_floats(g);
   // resized cut -> A; RandomPerspective for the cuts that drew it A -> B; RandomErasing + rotation + normalise (A or B) -> out
-  APH_LAUNCH(crop_resize_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, rgb, (const int*)table, (void*)A, g);
+  launch_crop_resize<APH_OUT_NCHW_RAW>(rgb, (const int*)table, (void*)A, g, ws, st);
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
@@ -765,7 +814,7 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
     if (rc) return rc;
     return aph_check_launch("aph_sample_bwd");
   }
-  float* dA = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g));
+  float* dA = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g) + strip_bytes(g));
   float* dB = dA + scratch_floats(g);
   const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);

@@ -152,8 +152,8 @@ def sample_fwd(geom, rgb, table, aug=None, tmp=None, out=None, out_mode=_ffi.APH
     shape, dtype = sample_out_shape(geom, out_mode)
     if out is None:
         out = torch.empty(shape, dtype=dtype, device=rgb.device)
-    if aug is not None and tmp is None:
-        tmp = sample_ws(geom, True, rgb.device, L)
+    if tmp is None:
+        tmp = sample_ws(geom, aug is not None, rgb.device, L)
     L.call('aph_sample_fwd', byref(geom), ptr(rgb), ptr(table), ptr(aug), ptr(tmp), ptr(out), int(out_mode), _stream(rgb))
     return out
 

@@ -110,12 +110,12 @@ typedef struct aph_sample_geom {
  * (h=0: none), [13] cos(angle), [14] sin(angle), [15] has_rotation (transforms_fast always 1) */
 
 /* bytes of the caller-owned device workspace d_ws of one forward/backward pair on geometry g (per-cut tap tables of the
- * crop adjoint; with_aug != 0 adds the cut scratch of the geometric augmentations).  The library never allocates in a
+ * crop adjoint, per-XCD work lists of the forward; with_aug != 0 adds the cut scratch of the geometric augmentations).  The library never allocates in a
  * launch path, so the calls can be captured into a hipGraph that stays valid as long as the caller's buffers do. */
 size_t aph_sample_ws_bytes(const aph_sample_geom* g, int with_aug);
 /* d_rgb [3,H,W] f32; d_table int32 [S,3] rows (csize, offx, offy) (utils.py:245-247);
- * d_aug f32 [S,16] or NULL (no geometric augmentation); d_ws: see aph_sample_ws_bytes (may be NULL
- * when d_aug == NULL).  out layout per out_mode. */
+ * d_aug f32 [S,16] or NULL (no geometric augmentation); d_ws: see aph_sample_ws_bytes (required).
+ * out layout per out_mode. */
 int aph_sample_fwd(const aph_sample_geom* g, const float* d_rgb, const int32_t* d_table, const float* d_aug,
                    void* d_ws, void* d_out, int out_mode, void* stream);
 /* adjoint.  d_out_grad: f32 in the layout of out_mode (patch-major f32 for APH_OUT_PATCH_F16; patch-major f16 for
