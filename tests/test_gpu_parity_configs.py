@@ -403,3 +403,42 @@ def test_illustrip_frame_loop_vs_oracle(b32, gen):
         # Adam with a fresh state moves every coordinate by ~lr * sign(g): a coordinate whose tiny gradient differs in sign is 2 lr off
         assert (new - cur).abs().mean().item() < 3e-3 * max(scale, 1.0), (gen, frame, (new - cur).abs().mean().item())
         assert eng.step_count == 1
+
+
+# ------------------------------------------------------------------------------------------------ CLI variants of the step
+@pytest.mark.parametrize('align', ['overscan', 'central', 'overmax'])
+def test_align_modes_step_vs_oracle(b32, align):
+    """--align variants (utils.py:222-237): wrap-padded overscan frames and the clipped-normal `central` offsets, one whole step"""
+    h, w, S = 256, 320, 6
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), rng='reference', align=align, use_graph=False)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, align=align)
+    seed_all(40)
+    table = R.draw_crop_table(S, 224, h, w, align, 0.4)
+    got, want = float(eng.step(table)), run.step(table)
+    assert abs(got - want) < 3e-4, (align, got, want)
+    compare_grad(eng.grad, run.params.grad, 0.999, 5e-2)
+
+
+@pytest.mark.parametrize('opt', ['adam', 'adamw', 'adamw_custom'])
+def test_optimizer_variants_noise_and_progressive_lr_vs_oracle(b32, opt):
+    """-opt variants (clip_fft.py:108-115), --noise (the spectrum shift of clip_fft.py:238 / image.py:166-167) and --prog
+    (clip_fft.py:288-291), three free-running steps"""
+    h, w, S, steps = 256, 320, 4, 3
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], transform=transforms.normalize(), rng='reference', optimizer=opt, lr=0.001)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0, optimizer=opt, lr=0.001)
+    for i in range(steps):
+        seed_all(50 + i)
+        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+        shift = 0.05 * torch.rand(1, 1, h, w // 2 + 1, 1)                                     # clip_fft.py:238
+        lr = 0.001 + (i / steps) * 0.099                                                       # clip_fft.py:288-291 (lr0 = 0.01 lr1, lr1 = 2 lrate)
+        got = float(eng.step(table, lr=lr, shift=shift.reshape(h, w // 2 + 1).to(DEV).contiguous()))
+        want = run.step(table, lr=lr, shift=shift)
+        assert abs(got - want) < 5e-4, (opt, i, got, want)
+    d = (eng.params.cpu().reshape(-1) - run.params_flat()).abs()
+    assert d.mean().item() < 2e-3, (opt, d.mean().item())
