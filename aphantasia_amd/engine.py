@@ -142,6 +142,7 @@ class Engine:
         self.ws = torch.empty(Sl * (len(self.coef) + 2), **f32)
         self.hyper = torch.empty(8, **f32)
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.dev)      # [skipped-step count, scratch]
+        self._own_stream = None
         self._stage, self._stage_i = None, 0       # pinned host ring for the per-step H2D refreshes (built lazily, GPU only)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
         self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
@@ -389,6 +390,18 @@ class Engine:
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):
         """One train(i).  Returns the (device) loss tensor of THIS step -- do not .item() it every step."""
+        if self.world > 1 and self.params.is_cuda:
+            # Multi-rank: the step (and with it the RCCL all-reduce) runs on a stream of its own rather than on the legacy
+            # default (NULL) stream, whose implicit synchronisation with every blocking stream is a bad neighbour for a
+            # collective library's internal streams.  The caller's stream is fenced on entry and exit.
+            if self._own_stream is None:
+                self._own_stream = torch.cuda.Stream(device=self.dev)
+            cur = torch.cuda.current_stream(self.dev)
+            self._own_stream.wait_stream(cur)
+            with torch.cuda.stream(self._own_stream):
+                out = self._step(table, augs, lr, shift, tables2)
+            cur.wait_stream(self._own_stream)
+            return out
         return self._step(table, augs, lr, shift, tables2)
 
     def _step(self, table, augs, lr, shift, tables2):
@@ -434,7 +447,12 @@ class Engine:
             if self.sim and 'ang' in str(self.sim) and self.rank != 0:
                 t -= sum(self.coef)          # the constant of 'ang' is counted once
             if self.comm is not None:
-                self.comm.all_reduce_(t)
+                # same stream as the step's collective: operations of one communicator must not overlap
+                st = self._own_stream if self._own_stream is not None else torch.cuda.current_stream(self.dev)
+                st.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(st):
+                    self.comm.all_reduce_(t)
+                torch.cuda.current_stream(self.dev).wait_stream(st)
             else:
                 import torch.distributed as dist
                 dist.all_reduce(t, group=self.pg)
