@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const float* __restric
   }
 }
 
+// y += alpha * x (the --enforce path adds the second cut set's image gradient / encoding gradient / loss term)
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
 __global__ void grad_guard_kernel(const float* __restrict__ g, size_t n, int* __restrict__ guard) {
   bool bad = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -247,6 +252,19 @@ int aph_linear_head(const float* d_enc, int S, int D, const float* d_w, float bi
     return aph_fail(APH_ERR_ARG, "aph_linear_head: bad argument (S=%d D=%d)", S, D);
   APH_LAUNCH(linear_head_kernel, dim3(1), dim3(256), sizeof(float) * S, (hipStream_t)stream_, d_enc, S, D, d_w, bias, coef, denom, gscale, d_loss, d_genc);
   return aph_check_launch("aph_linear_head");
+  APH_CATCH
+}
+
+// d_y[i] += alpha * d_x[i]: sums of partial results inside the step (clip_fft.py:271-275 --enforce: two cut sets contribute
+// to one image gradient), kept on the C ABI so that no framework op runs on the path
+int aph_axpy_f32(float* d_y, const float* d_x, float alpha, size_t n, void* stream_) {
+  APH_TRY
+  if (!d_y || !d_x) return aph_fail(APH_ERR_ARG, "aph_axpy_f32: null argument");
+  if (n == 0) return APH_OK;
+  unsigned grid = (unsigned)((n + 255) / 256);
+  grid = grid > 2048u ? 2048u : grid;
+  APH_LAUNCH(axpy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, d_y, d_x, alpha, n);
+  return aph_check_launch("aph_axpy_f32");
   APH_CATCH
 }
 

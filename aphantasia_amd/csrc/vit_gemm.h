@@ -5,8 +5,9 @@
 // Both operands are K-contiguous, so the forward (activations x weight^T) and the dgrad (d_out x weight, using a
 // pre-transposed weight copy) run through the same kernels.  Tile configurations (launch_gemm picks one per shape):
 //   * 256x256x64 "phased" kernel (gemm8_f16_kernel): 8 waves (2x4 of 128x64), 2 x 64 KiB stages, four phases per k-tile,
-//     the two wave groups one barrier apart -- wide outputs (N >= 2304) at full batch;
-//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS -- N = 768 at full batch;
+//     the two wave groups one barrier apart -- shapes with >= 400 such tiles: fc1 / fc2^T / patch-embed dgrad (N = 3072) at full
+//     batch (456 tiles).  QKV (N = 2304: 342 tiles = 1.34 rounds of 256 CUs) is NOT among them;
+//   * 256x128x64, 8 waves (4x2 of 64x64), 3-stage ring, 144 KiB LDS -- QKV and every N = 768 GEMM at full batch;
 //   * 128x128x64, 8 waves (4x2 of 32x64), 4-stage ring, 128 KiB LDS -- half-batch shards, wide outputs of small shards;
 //   *  64x 64x64, 4 waves (2x2 of 32x32), 4-stage ring,  64 KiB LDS (2 workgroups per CU) -- small M; two-pass split-K
 //     when only a handful of tiles exist (the class-row GEMMs of the last block).
@@ -655,7 +656,8 @@ inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, in
 }
 
 // tile choice, from the measured sweep over the ViT-B shapes at 1/2/4/8-rank shard sizes (tools/exp/tune_table.py):
-//   256x256 phased   wide outputs with >= 400 such tiles (N >= 2304 at full batch)
+//   256x256 phased   wide outputs with >= 400 such tiles (N = 3072 at full batch: 456; QKV's 342 tiles take the 256x128 path --
+//                    forcing every GEMM through 256x128 instead measured 136.1 vs 139.0 steps/s, profiles/r02_ab_mfma32.txt)
 //   256x128          >= 160 tiles
 //   128x128, 8 waves, 4-stage ring   >= 160 such tiles (half-batch shards with N = 768, wide outputs of small shards)
 //   64x64 (2 workgroups per CU)      everything smaller; split-K when only a handful of tiles exist

@@ -257,8 +257,8 @@ class Engine:
             L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), smp_scale, ops.ptr(self.table), ops.ptr(self.aug),
                    ops.ptr(self.tmp), ops.ptr(self.grgb), gmode, st)
             if self.enforce != 0:
-                self.grgb.add_(self.grgb2)
-                self.loss.add_(self.loss2)
+                L.call('aph_axpy_f32', ops.ptr(self.grgb), ops.ptr(self.grgb2), 1.0, self.grgb.numel(), st)
+                L.call('aph_axpy_f32', ops.ptr(self.loss), ops.ptr(self.loss2), 1.0, 1, st)
         else:
             self.grgb.zero_()
             self.loss.zero_()
@@ -306,7 +306,7 @@ class Engine:
         L.call('aph_sample_bwd', ctypes_byref(self.geom), ops.ptr(self.gpatch), smp_scale, ops.ptr(self.table2), ops.ptr(self.aug2),
                ops.ptr(self.tmp), ops.ptr(self.grgb2), gmode, st)
         pair_term(self.enc, self.enc2, self.loss2, self.genc2)       # same value again; genc2 now = d/d enc (first set)
-        self.genc.add_(self.genc2)
+        L.call('aph_axpy_f32', ops.ptr(self.genc), ops.ptr(self.genc2), 1.0, self.genc.numel(), st)
         L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table), ops.ptr(self.aug), ops.ptr(self.tmp),
                ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
         self.visual._forward_patches(self.patches, Sl, self.enc)

@@ -8,6 +8,7 @@ run consumes the same random stream -- and the HIP sampler applies all cuts in o
 (csrc/sampler.hip).  `-tf custom` / `-tf elastic` (kornia-based, non-default) are not provided.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -54,6 +55,7 @@ def normalize():
 transforms_fast = _Fast()
 
 
+_EXACT_ZERO_ROT = os.environ.get('APH_EXACT_ZERO_ROTATION') == '1'
 _RI = torch.empty(1, dtype=torch.int64)
 _RU = torch.empty(1)
 
@@ -111,7 +113,12 @@ def pack_aug(prms):
         ang = p.get('angle')
         if ang is not None:
             rot = math.radians(float(ang))
-            t[s, 13], t[s, 14], t[s, 15] = math.cos(rot), math.sin(rot), 1.0
+            # 0 degrees (21 of the 80 choices of random_rotate_fast, transforms.py:168): upstream still resamples the cut through an
+            # identity grid (torchvision's affine has no shortcut), which moves values by <= 2e-5 through the grid's fp32 rounding.
+            # The sampler copies instead (has_rotation = 0): a documented deviation far inside the parity tolerance that saves a
+            # quarter of the rotation kernels' work.  APH_EXACT_ZERO_ROTATION=1 restores the resampling.
+            has_rot = 1.0 if (float(ang) != 0.0 or _EXACT_ZERO_ROT) else 0.0
+            t[s, 13], t[s, 14], t[s, 15] = math.cos(rot), math.sin(rot), has_rot
     return t
 
 
@@ -160,7 +167,8 @@ def draw_fast_bulk(S, size, rng):
     # random_rotate_fast
     ang = np.asarray(ROT_ANGLES_FAST, dtype=np.float64)[rng.integers(0, len(ROT_ANGLES_FAST), size=S)]
     rot = np.radians(ang)
-    t[:, 13], t[:, 14], t[:, 15] = np.cos(rot), np.sin(rot), 1.0
+    t[:, 13], t[:, 14] = np.cos(rot), np.sin(rot)
+    t[:, 15] = 1.0 if _EXACT_ZERO_ROT else (ang != 0.0)          # 0 degrees: copy instead of an identity resampling (see pack_aug)
     return t
 
 

@@ -172,6 +172,10 @@ int aph_sim_loss(const float* d_enc, int S, int D, const float* d_targets, const
 int aph_linear_head(const float* d_enc, int S, int D, const float* d_w, float bias, float coef, float denom, float gscale,
                     float* d_loss, float* d_genc, void* stream);
 
+/* d_y[i] += alpha * d_x[i] -- partial results summed inside a step (--enforce, clip_fft.py:271-275: two cut sets contribute to
+ * one image gradient and one loss) */
+int aph_axpy_f32(float* d_y, const float* d_x, float alpha, size_t n, void* stream);
+
 /* ---- optimiser: torch.optim.Adam / AdamW as configured at clip_fft.py:108-115 --------------- */
 /* d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale};
  * d_m may be NULL when beta1 == 0, d_vmax NULL unless amsgrad; decoupled_wd = AdamW */
