@@ -153,7 +153,7 @@ def test_bulk_draws_have_the_reference_distributions(align):
         assert abs(a.std() - b.std()) < 0.08 * a.std() + 1e-9, (col, a.std(), b.std())
     big = 0.9 * min(h, w)
     assert abs((ta[:, 0] >= big).mean() - (tb[:, 0] >= big).mean()) < 0.04                  # macro share (~0.4 + tail)
-    for flag_col, p in ((8, 0.2), (15, 1.0)):                # perspective probability, rotation always on
+    for flag_col, p in ((8, 0.2), (15, 59.0 / 80.0)):        # perspective probability; rotation stage on for the non-zero angles (59 of 80 choices)
         assert abs((aa[:, flag_col] != 0).mean() - p) < 0.03 and abs((ab[:, flag_col] != 0).mean() - p) < 0.03
     assert abs((aa[:, 11] > 0).mean() - (ab[:, 11] > 0).mean()) < 0.04                      # erase probability
     za, zb = (np.abs(aa[:, 14]) < 1e-7).mean(), (np.abs(ab[:, 14]) < 1e-7).mean()           # share of angle 0 (21 of 80 choices)
