@@ -157,6 +157,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 #endif
 }
 
+// a value that is the same in every lane of the wave (e.g. the wave index), moved to a scalar register
+__device__ __forceinline__ int wave_uniform(int v) {
+#ifdef APH_EMU
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // all of this wave's LDS reads have returned
 __device__ __forceinline__ void wait_lgkm0() {
 #ifndef APH_EMU

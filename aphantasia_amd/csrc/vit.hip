@@ -395,7 +395,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || (tile_cfg >= 8 && tile_cfg <= 10) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && N % 256))
+      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || (tile_cfg >= 8 && tile_cfg <= 10) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;

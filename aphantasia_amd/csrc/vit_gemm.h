@@ -326,68 +326,69 @@ __device__ __forceinline__ void mfma_prio(int on) {
 
 template <class Epi, bool M32 = false>
 __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb,
-                                                        int M, int N, int K, Epi epi) {
+                                                        int M, int N, int K, Epi epi, int ntiles) {
   using C = Gemm8;
   APH_DYN_SMEM(smem);
   half_t* lds = reinterpret_cast<half_t*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  int m0, n0;
+  // PERSISTENT TILE LOOP.  The grid is min(ntiles, CUs) workgroups (one per CU: 128 KiB of LDS); workgroup b runs on XCD
+  // b % 8 (observed dispatch, speed only).  XCD x owns one contiguous run of tiles (n-tiles fastest, so the tiles in flight
+  // on one L2 share A panels); its workgroups walk that run with stride = workgroups on the XCD.  With gridDim.x == ntiles
+  // this is the one-tile-per-workgroup order of the ring kernels.  Bijective for any grid size.
+  int tile, tile_end, tile_step;
   {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int ntn = N / C::BN;
-    const int tm = tile / ntn;
-    n0 = (tile - tm * ntn) * C::BN;
-    m0 = tm * C::BM;
+    const int nwg = gridDim.x, b = blockIdx.x, G = nwg < 8 ? nwg : 8;      // G = 8 on the device whenever ntiles >= 8
+    const int q = ntiles / G, r = ntiles - q * G, xcd = b % G;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile_end = start + q + (xcd < r ? 1 : 0);
+    tile_step = (nwg - xcd + G - 1) / G;
+    tile = start + b / G;
   }
+  const int ntn = N / C::BN;
   // DMA shares: half-tile X, instruction i of this wave covers 8 consecutive tile rows starting at row0(X, i)
   const int lrow = lane >> 3, pc = lane & 7;
-  const half_t* gA[2][2];       // [half][i]
-  const half_t* gB[2];          // [i], half 0; half 1 = + 32 rows
-  int dA[2][2], dB[2][2];       // LDS offsets (halfs) inside a stage
+  // operand addresses = wave-uniform base (SGPR pair: matrix + k offset) + a 32-bit per-lane byte offset (the instruction's
+  // saddr form): 6 VGPRs instead of 6 pointers, and no vector address arithmetic in the main loop
+  unsigned oA[2][2];            // [half][i]
+  unsigned oB[2];               // [i], half 0; half 1 = + 32 rows (folded into the scalar base)
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int t) {     // operand offsets of tile t
+    const int tm = t / ntn;
+    n0 = (t - tm * ntn) * C::BN;
+    m0 = tm * C::BM;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q0 = (wave * 2 + i) * 8;
+    for (int i = 0; i < 2; ++i) {
+      const int q0 = (wave * 2 + i) * 8;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row0 = (q0 >> 6) * 128 + h * 64 + (q0 & 63), row = row0 + lrow;
-      int am = m0 + row; am = am < M ? am : M - 1;
-      gA[h][i] = A + (size_t)am * lda + ((pc ^ ((row >> 1) & 7)) << 3);
-      dA[h][i] = row0 * GEMM_BK;
-      const int brow0 = (q0 >> 5) * 64 + h * 32 + (q0 & 31);
-      dB[h][i] = C::BM * GEMM_BK + brow0 * GEMM_BK;
-      if (h == 0) gB[i] = Bt + (size_t)(n0 + brow0 + lrow) * ldb + ((pc ^ (((brow0 + lrow) >> 1) & 7)) << 3);
+      for (int h = 0; h < 2; ++h) {
+        const int row = (q0 >> 6) * 128 + h * 64 + (q0 & 63) + lrow;
+        int am = m0 + row; am = am < M ? am : M - 1;
+        oA[h][i] = ((unsigned)am * (unsigned)lda + ((pc ^ ((row >> 1) & 7)) << 3)) * 2u;
+      }
+      const int brow = (q0 >> 5) * 64 + (q0 & 31) + lrow;
+      oB[i] = ((unsigned)(n0 + brow) * (unsigned)ldb + ((pc ^ ((brow >> 1) & 7)) << 3)) * 2u;
     }
-  }
-  const size_t bhalf = (size_t)32 * ldb;
+  };
+  const char* Ab = reinterpret_cast<const char*>(A);
+  const char* Bb = reinterpret_cast<const char*>(Bt);
+  const size_t bhalf = (size_t)32 * ldb * 2;
   auto issue_a = [&](int h, int kt, half_t* stage) {
+    const char* base_k = Ab + (size_t)kt * (GEMM_BK * 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(gA[h][i] + kt * GEMM_BK, stage + dA[h][i]);
+    for (int i = 0; i < 2; ++i) glds16(base_k + oA[h][i], stage + (((wave * 2 + i) >> 3) * 128 + h * 64 + (((wave * 2 + i) * 8) & 63)) * GEMM_BK);
   };
   auto issue_b = [&](int h, int kt, half_t* stage) {
+    const char* base_k = Bb + (size_t)kt * (GEMM_BK * 2) + (h ? bhalf : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(gB[i] + (h ? bhalf : 0) + kt * GEMM_BK, stage + dB[h][i]);
+    for (int i = 0; i < 2; ++i)
+      glds16(base_k + oB[i], stage + C::BM * GEMM_BK + (((wave * 2 + i) >> 2) * 64 + h * 32 + (((wave * 2 + i) * 8) & 31)) * GEMM_BK);
   };
 
   // accumulators and fragments: 16x16x32 -> acc[8][4] f32x4, A [row tile 16][k32 step], B [half][col tile 16][k32 step];
   //                             32x32x16 -> acc32[4][2] f32x16, A [row tile 32][k16 step], B [half][k16 step] (one 32-col tile per half)
   f32x4 acc[M32 ? 1 : 8][M32 ? 1 : 4];
   f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
-  if constexpr (M32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   half8 fa[4][2], fb[2][2][2];
   half8 ga[2][4], gb[2][4];
   const int frow = M32 ? (lane & 31) : (lane & 15);
@@ -436,67 +437,119 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
   };
 
   const int nk = K / GEMM_BK;
-  issue_a(0, 0, lds); issue_b(0, 0, lds); issue_b(1, 0, lds); issue_a(1, 0, lds);
-  wait_vm_barrier<0>();
   const bool lead = wr == 0;
-  if (!lead) wait_vm_barrier<63>();            // trailing group: one barrier behind from here on
-  for (int kt = 0; kt < nk; ++kt) {
-    half_t* cur = lds + (kt & 1) * C::STAGE;
-    half_t* nxt = lds + ((kt + 1) & 1) * C::STAGE;
-    const bool more = kt + 1 < nk;
-    // phase 1: quadrant (A0, B0)
-    read_a(0, cur); read_b(0, cur);
-    if (more) issue_a(0, kt + 1, nxt);
-    phase_barrier(!lead, !more);
-    quadrant(0, 0);
-    phase_barrier(lead, !more);
-    // phase 2: (A0, B1)
-    read_b(1, cur);
-    if (more) issue_b(0, kt + 1, nxt);
-    phase_barrier(!lead, !more);
-    quadrant(0, 1);
-    phase_barrier(lead, !more);
-    // phase 3: (A1, B1)
-    read_a(1, cur);
-    if (more) issue_b(1, kt + 1, nxt);
-    phase_barrier(false, false);
-    quadrant(1, 1);
-    phase_barrier(false, false);
-    // phase 4: (A1, B0) -- nothing to read
-    if (more) issue_a(1, kt + 1, nxt);
-    phase_barrier(!lead, false);
-    quadrant(1, 0);
-    phase_barrier(lead, false);
-  }
-  if (lead) wait_vm_barrier<63>();             // balance the trailing group's extra barrier
-  __syncthreads();
-  float* ct = reinterpret_cast<float*>(smem) + wave * (C::EP_MT * 16 * C::CT_LD);
-#pragma unroll
-  for (int p0 = 0; p0 < 8; p0 += C::EP_MT) {
-    wave_lds_fence();
+  int base = 0;                                  // k-tile kt of the current tile lives in stage (base + kt) & 1
+  setup(tile);
+  issue_a(0, 0, lds); issue_b(0, 0, lds); issue_b(1, 0, lds); issue_a(1, 0, lds);
+  for (;;) {
     if constexpr (M32) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(ct + (lane & 31) * C::CT_LD + nt * 32 + 8 * g + 4 * (lane >> 5)) =
-              f32x4{acc32[p0 / 2][nt][4 * g], acc32[p0 / 2][nt][4 * g + 1], acc32[p0 / 2][nt][4 * g + 2], acc32[p0 / 2][nt][4 * g + 3]};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
     } else {
 #pragma unroll
-      for (int mt = 0; mt < C::EP_MT; ++mt)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          *reinterpret_cast<f32x4*>(ct + (mt * 16 + (lane & 15)) * C::CT_LD + nt * 16 + (lane >> 4) * 4) = acc[p0 + mt][nt];
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    wave_lds_fence();
+    // k-tile 0 has landed (issued above, or under the previous tile's epilogue); the previous tile's staging reads and
+    // stores are behind every wave
+    wait_vm_barrier<0>();
+    if (!lead) wait_vm_barrier<63>();            // trailing group: one barrier behind from here on
+    for (int kt = 0; kt < nk; ++kt) {
+      half_t* cur = lds + ((base + kt) & 1) * C::STAGE;
+      half_t* nxt = lds + ((base + kt + 1) & 1) * C::STAGE;
+      const bool more = kt + 1 < nk;
+      // phase 1: quadrant (A0, B0)
+      read_a(0, cur); read_b(0, cur);
+      if (more) issue_a(0, kt + 1, nxt);
+      phase_barrier(!lead, !more);
+      quadrant(0, 0);
+      phase_barrier(lead, !more);
+      // phase 2: (A0, B1)
+      read_b(1, cur);
+      if (more) issue_b(0, kt + 1, nxt);
+      phase_barrier(!lead, !more);
+      quadrant(0, 1);
+      phase_barrier(lead, !more);
+      // phase 3: (A1, B1)
+      read_a(1, cur);
+      if (more) issue_b(1, kt + 1, nxt);
+      phase_barrier(false, false);
+      quadrant(1, 1);
+      phase_barrier(false, false);
+      // phase 4: (A1, B0) -- nothing to read
+      if (more) issue_a(1, kt + 1, nxt);
+      phase_barrier(!lead, false);
+      quadrant(1, 0);
+      phase_barrier(lead, false);
+    }
+    if (lead) wait_vm_barrier<63>();             // balance the trailing group's extra barrier
+    __syncthreads();                             // both stages are dead
+    // Next tile's k-tile 0 streams in UNDER this tile's epilogue: it goes to the stage that served k-tile nk-2; the accumulators
+    // are staged in the other one (k-tile nk-1's), so the two never meet.  The epilogue's stores drain while the next main
+    // loop runs out of L2.
+    base = (base + nk) & 1;
+    const int em0 = m0, en0 = n0;
+    const int next = tile + tile_step;
+    const bool has_next = next < tile_end;       // workgroup-uniform
+    if (has_next) {
+      setup(next);
+      half_t* st0 = lds + base * C::STAGE;
+      issue_a(0, 0, st0); issue_b(0, 0, st0); issue_b(1, 0, st0); issue_a(1, 0, st0);
+    }
+    if constexpr (M32) {
+      // one tile per workgroup only (launch_gemm8): padded staging from the start of the ring
+      float* ct = reinterpret_cast<float*>(smem) + wave * (C::EP_MT * 16 * C::CT_LD);
 #pragma unroll
-    for (int it = 0; it < C::EP_MT * 2; ++it) {
-      const int r = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
-      const int m = m0 + (wr * 8 + p0) * 16 + r;
-      if (m < M) epi.apply8(m, n0 + wc * 64 + c8, a, b);
+      for (int p0 = 0; p0 < 8; p0 += C::EP_MT) {
+        wave_lds_fence();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(ct + (lane & 31) * C::CT_LD + nt * 32 + 8 * g + 4 * (lane >> 5)) =
+                f32x4{acc32[p0 / 2][nt][4 * g], acc32[p0 / 2][nt][4 * g + 1], acc32[p0 / 2][nt][4 * g + 2], acc32[p0 / 2][nt][4 * g + 3]};
+        wave_lds_fence();
+#pragma unroll
+        for (int it = 0; it < C::EP_MT * 2; ++it) {
+          const int r = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * C::CT_LD + c8 + 4);
+          const int m = em0 + (wr * 8 + p0) * 16 + r;
+          if (m < M) epi.apply8(m, en0 + wc * 64 + c8, a, b);
+        }
+      }
+    } else {
+      // 8 KiB per wave inside the dead stage: 32 rows x 16 chunks of 16 bytes, chunk c of row r at c ^ (r & 15) (the
+      // 16 lanes of one accumulator column group hit 16 different chunks; a row's 8 readers too)
+      float* ct = reinterpret_cast<float*>(lds + (base ^ 1) * C::STAGE) + wave * (C::EP_MT * 16 * 64);
+#pragma unroll
+      for (int p0 = 0; p0 < 8; p0 += C::EP_MT) {
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < C::EP_MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int r = mt * 16 + (lane & 15);
+            *reinterpret_cast<f32x4*>(ct + r * 64 + (((nt * 4 + (lane >> 4)) ^ (r & 15)) << 2)) = acc[p0 + mt][nt];
+          }
+        wave_lds_fence();
+#pragma unroll
+        for (int it = 0; it < C::EP_MT * 2; ++it) {
+          const int r = it * 8 + (lane >> 3), j = (lane & 7) * 2;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ct + r * 64 + ((j ^ (r & 15)) << 2));
+          const f32x4 b = *reinterpret_cast<const f32x4*>(ct + r * 64 + (((j + 1) ^ (r & 15)) << 2));
+          const int m = em0 + (wr * 8 + p0) * 16 + r;
+          if (m < M) epi.apply8(m, en0 + wc * 64 + j * 4, a, b);
+        }
+      }
     }
+    if (!has_next) break;
+    tile = next;
   }
 }
 
@@ -643,15 +696,40 @@ inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int l
   APH_LAUNCH((splitk_reduce_kernel<Epi>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (const float*)sp.ws, splits, M, N, epi);
 }
 
+// workgroups of a persistent launch: one per CU of the current device (APH_GEMM8_PERSIST=0: one tile per workgroup, for A/B runs)
+inline int gemm8_persistent_wgs() {
+#ifdef APH_EMU
+  return 3;                                        // exercises the tile loop (and its remainders) under the interpreter
+#else
+  static const int persist = [] { const char* e = getenv("APH_GEMM8_PERSIST"); return e ? atoi(e) : 1; }();
+  if (!persist) return 1 << 30;
+  thread_local int dev_cached = -1, ncu = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1 << 30;
+  if (dev != dev_cached) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) return 1 << 30;
+    dev_cached = dev;
+  }
+  return ncu;
+#endif
+}
+
+// the phased kernel addresses its operands with 32-bit byte offsets from the matrix base
+inline bool gemm8_addressable(int M, int lda, int N, int ldb) {
+  return (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldb * 2 < ((size_t)1 << 32);
+}
+
 template <class Epi>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  const dim3 grid((N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM));
+  const int ntiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   if (gemm_mfma32()) {
     APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, true>), Gemm8::SMEM);
-    APH_LAUNCH((gemm8_f16_kernel<Epi, true>), grid, dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi);
+    APH_LAUNCH((gemm8_f16_kernel<Epi, true>), dim3(ntiles), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, ntiles);
   } else {
+    const int wgs = gemm8_persistent_wgs();
     APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, false>), Gemm8::SMEM);
-    APH_LAUNCH((gemm8_f16_kernel<Epi, false>), grid, dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi);
+    APH_LAUNCH((gemm8_f16_kernel<Epi, false>), dim3(ntiles < wgs ? ntiles : wgs), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K,
+               epi, ntiles);
   }
 }
 
@@ -668,7 +746,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
   static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)
-  if (N % Gemm8::BN == 0 && huge_tiles >= gemm8_min) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
+  if (N % Gemm8::BN == 0 && huge_tiles >= gemm8_min && gemm8_addressable(M, lda, N, ldb)) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {

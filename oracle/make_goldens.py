@@ -111,6 +111,28 @@ def gold_resume(ref, name):
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
+def gold_depth(name):
+    """the reference's own depth/depth.py grid_warp + depthwarp (depth.py:44-84) and illustrip.py's depth_transform inputs;
+    the estimator is oracle.depth_ref.toy_depth (Depth-Anything's weights are not in this image)"""
+    from oracle import depth_ref
+    d = shim.load_reference_depth()
+    g = torch.Generator().manual_seed(21)
+    H, W = 40, 56
+    img_t = torch.randn(1, 3, H, W, generator=g) * 0.7
+    img = torch.rand(1, 3, H, W, generator=g)
+    dep = torch.rand(1, H, W, generator=g)
+    out = dict(img_t=img_t.numpy(), img=img.numpy(), dep=dep.numpy())
+    out['warp_a'] = d.grid_warp(img_t, dep, H, W, 0.3, torch.as_tensor([0.1, -0.2]), 0.5).numpy()
+    out['warp_b'] = d.grid_warp(img_t, dep, H, W, 4.0, torch.as_tensor([1.5, 0.7]), 0.2, dlens=0.3).numpy()   # reflections
+    out['blur'] = d.triangle_blur(img, 5, 2).numpy()
+    out['resize_dn'] = d.resize(img, (28, 42)).numpy()
+    out['resize_up'] = d.resize(dep[None], (70, 75)).numpy()
+    # depthwarp with a small estimator resolution through a patched `res` is not possible (hard-coded 518, depth.py:71):
+    # run it as written -- a 40x56 frame gives a 518x714 estimator input
+    out['depthwarp'] = d.depthwarp(img_t, img, depth_ref.toy_depth, 0.4, [0.2, -0.1], 0.6).numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = shim.load_reference()
@@ -118,6 +140,7 @@ def main():
     gold_synth(ref, 45, 63, 'synth_45x63.npz', colors=1.0, decay=1.0, contrast=1.0)   # odd sizes
     gold_slice(ref, 'slice_48x80.npz')
     gold_sim(ref, 'sim.npz')
+    gold_depth('depthwarp_40x56.npz')
     gold_run(ref, 'run_40x56.npz')
     gold_resume(ref, 'resume_img.npz')
     print('goldens written to', OUT)

@@ -82,6 +82,7 @@ def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(2100, 128, 192)])          # 256x128 tile config
     K.check_gemm(emu, 'cpu', [(520, 256, 128)])           # 64x64 tile config at a ragged M
     K.check_gemm(emu, 'cpu', [(300, 256, 192), (260, 512, 64)], tile_cfg=4)   # phased 256x256 kernel (offset wave groups)
+    K.check_gemm(emu, 'cpu', [(700, 768, 192), (1100, 512, 128)], tile_cfg=4, variants=(0,))   # persistent tile loop: 9 / 10 tiles on 3 workgroups, odd and even k-tile counts
     K.check_gemm(emu, 'cpu', [(150, 128, 512), (64, 128, 256)], tile_cfg=9)   # split-K x4, two-pass ordered reduction
     K.check_gemm(emu, 'cpu', [(70, 128, 192)], tile_cfg=8)
     K.check_gemm(emu, 'cpu', [(200, 256, 320)], tile_cfg=10)   # 128x128, 8 waves, 4-stage ring

@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aphantasia_amd import _ffi
 from aphantasia_amd.ops import ptr, _stream
 L = _ffi.lib()
-for (M, N, K) in [(9500, 3072, 768), (3072, 3072, 768), (8192, 8192, 8192)]:
+for (M, N, K) in [(9500, 3072, 768), (18715, 3072, 768), (3072, 3072, 768), (8192, 8192, 8192)]:
     A = torch.randn(M, K, device='cuda').half(); B = torch.randn(N, K, device='cuda').half(); C = torch.empty(M, N, device='cuda')
     st = _stream(A)
     line = '%5d x %5d x %5d :' % (M, N, K)
-    for cfg in (1, 2, 4, 10):
+    for cfg in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 10)):
         f = lambda: L.call('aph_gemm_f16_ld', ptr(A), K, ptr(B), K, M, N, K, ptr(C), cfg, st)
         for _ in range(3): f()
         torch.cuda.synchronize()
