@@ -10,8 +10,11 @@ Everything device-side runs through the C ABI: aph_frame_affine, aph_irfft2 / ap
 Nothing is allocated per frame: Engine.reset_params copies the warped picture into the existing leaf and zeroes the Adam
 moments in place, so captured hipGraphs stay valid across frames.
 
-Not here (SURVEY.md section 8f rank 4 / section 2 out of scope): the depth warp (needs Depth-Anything weights), the text-file /
-multi-line prompt scheduling and `latent_anima` motion curves of the illustrip.py command line (pass per-frame motion
+Depth (illustrip.py:387-388,396-397,404-405): with `depth` > 0 the picture goes through depth_transform (depthwarp.py: blur,
+bicubic resize, the caller's depth ESTIMATOR, aph_grid_warp) before the affine.  The estimator (Depth-Anything-V2 upstream)
+is the `depth_fn` callable -- its weights are not part of this repository.
+
+Not here (SURVEY.md section 2 out of scope): the text-file / multi-line prompt scheduling and `latent_anima` motion curves of the illustrip.py command line (pass per-frame motion
 values to `frame()` yourself), LPIPS.
 """
 import torch
@@ -20,7 +23,8 @@ from . import ops, transforms
 
 
 class FrameLoop:
-    def __init__(self, engine, gen='RGB', opt_step=1, smooth=False, engine2=None, dualmod=None):
+    def __init__(self, engine, gen='RGB', opt_step=1, smooth=False, engine2=None, dualmod=None, depth=0.0, depth_fn=None, colors=1.0,
+                 depth_dir=None, depth_res=518):
         """engine: aphantasia_amd.engine.Engine with param_kind 'pixel' (gen RGB: rgb_priors=True as illustrip.py:438-440) or
         'fft' (gen FFT); engine2 + dualmod: the ViT-B/16 engine sharing its parameters / optimiser state (illustrip.py:372)."""
         self.eng, self.eng2, self.dualmod = engine, engine2, dualmod
@@ -33,17 +37,28 @@ class FrameLoop:
         self.smooth = bool(smooth) and self.gen == 'FFT'           # illustrip.py:97-100: RGB forces smooth off
         self.h, self.w = engine.h, engine.w
         self.frames = 0
+        self.depth, self.depth_fn, self.colors, self.depth_dir, self.depth_res = float(depth), depth_fn, colors, depth_dir, depth_res
+        if self.depth > 0 and depth_fn is None:
+            raise ValueError('depth > 0 needs depth_fn: a callable [1,3,h,w] in (0,1) -> depth [1,1,h,w] (depthwarp.InferDepthAny upstream)')
         self._img = torch.empty(3, self.h, self.w, dtype=torch.float32, device=engine.dev) if self.gen == 'FFT' else None
         self._spec = torch.empty_like(engine.params) if self.gen == 'FFT' else None
 
     def reparameterise(self, scale, shift, angle, shear):
         """MOTION (illustrip.py:381-409) + the optimiser restart (:411-423)"""
         e = self.eng
+
+        def deep(x):                                                                                         # illustrip.py:387-388 / :404-405
+            if self.depth <= 0:
+                return x
+            from . import depthwarp
+            return depthwarp.depth_transform(x, self.depth_fn, self.depth, scale, shift, self.colors, self.depth_dir, self.frames,
+                                             res=self.depth_res, lib=e.lib)
         if self.gen == 'RGB':
-            new = transforms.frame_transform(e.params.detach(), (self.h, self.w), angle, shift, scale, shear, lib=e.lib)
+            new = transforms.frame_transform(deep(e.params.detach().reshape(1, 3, self.h, self.w)), (self.h, self.w), angle, shift, scale, shear,
+                                             lib=e.lib)
         else:
             ops.irfft2(e.plan, e.params.detach(), out=self._img, lib=e.lib)                                  # illustrip.py:401-403
-            img = transforms.frame_transform(self._img.reshape(1, 3, self.h, self.w), (self.h, self.w), angle, shift, scale, shear, lib=e.lib)
+            img = transforms.frame_transform(deep(self._img.reshape(1, 3, self.h, self.w)), (self.h, self.w), angle, shift, scale, shear, lib=e.lib)
             new = ops.rfft2(e.plan, img.reshape(3, self.h, self.w).contiguous(), out=self._spec, lib=e.lib)    # :407-408
         e.reset_params(new, keep_optimizer_state=self.smooth and self.frames > 0)
 

@@ -8,8 +8,10 @@ Per frame: warp the current picture by the frame's motion (scale / shift / angle
 restart the optimiser, take --opt_step optimisation steps against the prompt(s), save the frame (aphantasia_amd/
 illustrip_loop.py).  Built on the fused HIP engine; multi-GPU as clip_fft.py (cuts split over ranks, one RCCL all-reduce).
 
-Out of this path's scope: depth warp (-d, needs Depth-Anything weights), multi-line text files
-with topic interpolation, `latent_anima` motion curves (the motion here is the constant one of `--anima False`), --aest, LPIPS,
+-d / --depth runs the depth warp (depth/depth.py:41-84 on HIP kernels); its estimator, Depth-Anything-V2, is loaded by
+`transformers` from a LOCAL checkpoint directory (--depth_weights or APH_DEPTH_WEIGHTS; there is no network here) and is the one
+part of the frame that runs on stock PyTorch.
+Out of this path's scope: multi-line text files with topic interpolation, `latent_anima` motion curves (the motion here is the constant one of `--anima False`), --aest, LPIPS,
 -tf custom / elastic, translation.  The flags exist and are refused with a message instead of being silently ignored.
 """
 import argparse
@@ -49,7 +51,10 @@ def get_args(argv=None):
     p.add_argument('--shift', default=10., type=float)
     p.add_argument('--angle', default=0.8, type=float)
     p.add_argument('--shear', default=0.4, type=float)
-    p.add_argument('-d', '--depth', default=0, type=float)
+    p.add_argument('-d', '--depth', default=0, type=float, help='Add depth with such strength, if > 0')
+    p.add_argument('--depth_model', default='b', help='Depth Anything model: large, base or small')
+    p.add_argument('--depth_dir', default=None, help='Directory to save depth, if not None')
+    p.add_argument('--depth_weights', default=None, help='local Depth-Anything-V2 checkpoint directory (HF format); or APH_DEPTH_WEIGHTS')
     p.add_argument('-a', '--align', default='overscan', choices=['central', 'uniform', 'overscan', 'overmax'])
     p.add_argument('-tf', '--transform', default='fast', choices=['none', 'fast', 'custom', 'elastic'])
     p.add_argument('-opt', '--optimizer', default='adam_custom', choices=['adam', 'adam_custom', 'adamw', 'adamw_custom'])
@@ -99,8 +104,6 @@ def derate_samples(a):
 
 def main(argv=None):
     a = get_args(argv)
-    if a.depth > 0:
-        raise SystemExit(' -d / --depth needs the Depth-Anything-V2 weights (depth/depth.py); the depth warp is not part of this path')
     if a.aest != 0 or a.transform in ('custom', 'elastic'):
         raise SystemExit(' --aest / -tf custom|elastic are not part of this path')
     if a.in_txt is None and a.in_txt2 is None:
@@ -145,7 +148,14 @@ def main(argv=None):
               expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
     eng = Engine(leaf, h, w, model, S, targets_for(model), **kw)
     eng2 = Engine(leaf, h, w, model2, S, targets_for(model2), state=eng.state(), **kw) if model2 is not None else None
-    loop = FrameLoop(eng, gen=a.gen, opt_step=a.opt_step, smooth=a.smooth, engine2=eng2, dualmod=a.dualmod)
+    depth_fn = None
+    if a.depth > 0:
+        from aphantasia_amd.depthwarp import InferDepthAny
+        depth_fn = InferDepthAny(a.depth_model, path=a.depth_weights)          # raises without a local checkpoint
+        if a.depth_dir is not None:
+            os.makedirs(a.depth_dir, exist_ok=True)
+    loop = FrameLoop(eng, gen=a.gen, opt_step=a.opt_step, smooth=a.smooth, engine2=eng2, dualmod=a.dualmod, depth=a.depth, depth_fn=depth_fn,
+                     colors=a.colors, depth_dir=a.depth_dir)
     name = txt_clean(a.in_txt or a.in_txt2).lower()[:40] + '-%s' % a.gen
     tempdir = os.path.join(a.out_dir, name)
     os.makedirs(tempdir, exist_ok=True)

@@ -127,6 +127,23 @@ int aph_sample_bwd(const aph_sample_geom* g, const void* d_out_grad, float gscal
  * [C,H,W] image (once per frame).  h_inv_matrix6: HOST pointer, row-major 2x3 inverse affine matrix (torchvision's
  * _get_inverse_affine_matrix with the image centre as origin).  d_dst must not alias d_src. */
 int aph_frame_affine(const float* d_src, int C, int H, int W, const float* h_inv_matrix6, float* d_dst, void* stream);
+/* ---- depth warp of the illustrip frame loop (/root/reference/depth/depth.py:41-84, illustrip.py:115-128) ----
+ * Everything but the depth ESTIMATOR (Depth-Anything-V2, depth.py:20-32, a third-party network): the caller runs it (or
+ * anything else) between aph_resize_bicubic and aph_flip_w and hands the depth map to aph_grid_warp.  All images f32,
+ * [C,H,W] contiguous; destinations must not alias sources.
+ *   aph_triangle_blur: d_dst = torch.lerp(src, triangle_blur(src, kernel_size, power), mix)   (utils.py:137-147; depth.py:75
+ *                      uses kernel_size 5, power 2, mix 0.5; mix = 1 is the plain blur).  kernel_size odd, <= 9.
+ *   aph_resize_bicubic: F.interpolate(src [C,h,w], (H,W), mode='bicubic', align_corners=True)          (depth.py:41-42)
+ *   aph_flip_w: d_dst = flip(src, [-1]), times d_mul elementwise when d_mul != NULL                     (depth.py:77)
+ *   aph_grid_warp: depth.py:44-66 -- two bilinear, reflection-padded, align_corners=True grid samples: the depth push
+ *                  grid + (centre - grid) * (depth - max(depth) * midpoint) * strength, then the lens stretch
+ *                  grid + (centre - grid) * |centre - grid| * strength * dlens.  d_depth [H,W]; centre in [-1,1] (x, y);
+ *                  d_ws: C*H*W + 256 floats of scratch (intermediate image + the depth maximum and its partials). */
+int aph_triangle_blur(const float* d_src, int C, int H, int W, int kernel_size, float power, float mix, float* d_dst, void* stream);
+int aph_resize_bicubic(const float* d_src, int C, int h, int w, float* d_dst, int H, int W, void* stream);
+int aph_flip_w(const float* d_src, const float* d_mul, int C, int H, int W, float* d_dst, void* stream);
+int aph_grid_warp(const float* d_img, const float* d_depth, int C, int H, int W, float strength, float centre_x, float centre_y,
+                  float midpoint, float dlens, float* d_ws, float* d_out, void* stream);
 /* NCHW f32 [S,3,R,R] <-> patch-major (entry of model.encode_image for a caller-made batch) */
 int aph_patchify_f16(const float* d_nchw, int S, int R, int patch, void* d_patches_f16, void* stream);
 int aph_unpatchify_f32(const float* d_patch_grad, int S, int R, int patch, float gscale, float* d_nchw_grad, void* stream);

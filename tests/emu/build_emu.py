@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'aphantasia_amd', 'csrc')
 OUT = os.path.join(HERE, 'build', 'libaphantasia_emu.so')
-SOURCES = ['api.hip', 'synth.hip', 'dwt.hip', 'sampler.hip', 'loss_adam.hip', 'vit.hip', 'comm.hip']
+SOURCES = ['api.hip', 'synth.hip', 'dwt.hip', 'sampler.hip', 'loss_adam.hip', 'vit.hip', 'comm.hip', 'depthwarp.hip']
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 

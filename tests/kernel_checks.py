@@ -423,3 +423,62 @@ def check_adam_guard(lib, dev):
         pc, vc = run(gb, True)
         assert torch.equal(pc, p0) and torch.equal(vc, v0)
     assert guard.cpu().tolist()[0] == 3
+
+
+def check_depthwarp(lib, dev, g, sizes=((40, 56), (37, 51), (64, 48))):
+    """csrc/depthwarp.hip vs (a) outputs of the reference's own depth/depth.py functions (golden `g`), (b) the oracle at
+    other sizes / parameters (reflections, odd sizes, centre outside the frame)"""
+    from aphantasia_amd import depthwarp as DW
+    from oracle import depth_ref
+    t = lambda k: torch.from_numpy(g[k])
+    img_t, img, dep = t('img_t'), t('img'), t('dep')
+    H, W = img.shape[-2:]
+    tol = lambda want: 2e-5 * max(1.0, want.abs().max().item())
+    got = DW.grid_warp(img_t.to(dev), dep.to(dev), H, W, 0.3, [0.1, -0.2], 0.5, lib=lib).cpu()
+    assert (got - t('warp_a')).abs().max().item() < tol(t('warp_a'))
+    got = DW.grid_warp(img_t.to(dev), dep.to(dev), H, W, 4.0, [1.5, 0.7], 0.2, dlens=0.3, lib=lib).cpu()
+    assert (got - t('warp_b')).abs().max().item() < 5 * tol(t('warp_b'))        # strength 4: coordinates far outside, several reflections
+    got = DW.triangle_blur(img.to(dev), 5, 2, lib=lib).cpu()
+    assert (got - t('blur')).abs().max().item() < 2e-6
+    got = DW.resize(img.to(dev), (28, 42), lib=lib).cpu()
+    assert (got - t('resize_dn')).abs().max().item() < 5e-6
+    got = DW.resize(dep[None].to(dev), (70, 75), lib=lib).cpu()
+    assert (got - t('resize_up')).abs().max().item() < 5e-6
+    dev_depth = lambda image: depth_ref.toy_depth(image.cpu()).to(dev)      # the estimator is the caller's business
+    got = DW.depthwarp(img_t.to(dev), img.to(dev), dev_depth, 0.4, [0.2, -0.1], 0.6, lib=lib).cpu()
+    assert (got - t('depthwarp')).abs().max().item() < tol(t('depthwarp'))
+    gen = torch.Generator().manual_seed(4)
+    for (h, w) in sizes:
+        x = torch.randn(1, 3, h, w, generator=gen)
+        d = torch.rand(1, h, w, generator=gen)
+        if h * w > 100000:
+            # A bilinear sample moves by (image gradient) x (coordinate error), and fp32 grid coordinates carry ~4e-5 px of rounding at
+            # 1280 px (torch's own linspace differs by 1 ulp between AVX2 and AVX-512 hosts): white noise at full size measures
+            # that, not the kernel.  Full-size frames are checked on a smooth picture (what the loop warps), noise at small sizes.
+            x = torch.nn.functional.interpolate(torch.randn(1, 3, h // 16, w // 16, generator=gen), (h, w), mode='bicubic', align_corners=False)
+            d = torch.nn.functional.interpolate(torch.rand(1, 1, h // 16, w // 16, generator=gen), (h, w), mode='bilinear')[0].clamp(0, 1)
+        cases = ((0.25, (0.0, 0.0), 0.5, 0.05), (-1.5, (-2.0, 0.3), 0.9, 0.5), (0.0, (0.3, 0.3), 0.5, 0.05))
+        if h * w > 100000:      # (an extreme warp folds the picture: pass 2 then samples gradients of several units per pixel -- small sizes only)
+            cases = ((0.25, (0.0, 0.0), 0.5, 0.05), (0.6, (0.3, -0.2), 0.7, 0.1), (0.0, (0.3, 0.3), 0.5, 0.05))
+        for (strength, centre, mid, dl) in cases:
+            want = depth_ref.grid_warp(x, d, h, w, strength, centre, mid, dl)
+            got = DW.grid_warp(x.to(dev), d.to(dev), h, w, strength, centre, mid, dl, lib=lib).cpu()
+            err = (got - want).abs()
+            rel = 3e-4 if h * w > 100000 else 1e-4          # full size: ~1e-4 px of fp32 coordinate rounding on either side
+            assert err.max().item() < rel * max(1.0, abs(strength)) * want.abs().max().item(), (h, w, strength, err.max().item())
+            assert err.mean().item() < 1e-5 * want.abs().max().item(), (h, w, strength, err.mean().item())
+        for (k, p, mix) in ((5, 2.0, 0.5), (3, 1.0, 1.0), (7, 1.5, 0.25)):
+            want = torch.lerp(x, depth_ref.triangle_blur(x, k, p), mix)
+            got = DW.triangle_blur(x.to(dev), k, p, mix=mix, lib=lib).cpu()
+            assert (got - want).abs().max().item() < 3e-6, (h, w, k)
+        for size in ((h * 2 + 1, w * 3), (h // 2, w // 3 + 1), (1, 1), (h, w)):
+            want = depth_ref.resize(x, size)
+            got = DW.resize(x.to(dev), size, lib=lib).cpu()
+            assert (got - want).abs().max().item() < 1e-5, (h, w, size)
+        want = torch.flip(x, [-1]) * x
+        got = DW.flip_w(x.to(dev), mul=x.to(dev), lib=lib).cpu()
+        assert torch.equal(got, want)
+    # zero strength: both passes are the identity grid -> the image itself (to interpolation rounding)
+    x = torch.randn(1, 3, 33, 47, generator=gen)
+    got = DW.grid_warp(x.to(dev), torch.rand(1, 33, 47, generator=gen).to(dev), 33, 47, 0.0, [0.4, 0.1], 0.5, lib=lib).cpu()
+    assert (got - x).abs().max().item() < 2e-5

@@ -120,3 +120,7 @@ def test_frame_affine(emu):
 
 def test_adam_guard(emu):
     K.check_adam_guard(emu, 'cpu')
+
+
+def test_depthwarp(emu, golden):
+    K.check_depthwarp(emu, 'cpu', golden('depthwarp_40x56.npz'), sizes=((37, 51),))

@@ -30,6 +30,11 @@ def test_fft_pair():
     K.check_fft_pair(None, DEV, 720, 1280)
 
 
+def test_depthwarp_vs_reference_golden_and_oracle(golden):
+    """depth.py:41-84 on the GPU: the reference's own outputs (golden) + the oracle at other sizes, incl. 720p"""
+    K.check_depthwarp(None, DEV, golden('depthwarp_40x56.npz'), sizes=((37, 51), (64, 48), (720, 1280)))
+
+
 def test_dwt():
     K.check_dwt(None, DEV, 'db3', 45, 70)
     K.check_dwt(None, DEV, 'coif2', 64, 96)

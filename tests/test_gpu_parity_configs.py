@@ -405,6 +405,43 @@ def test_illustrip_frame_loop_vs_oracle(b32, gen):
         assert eng.step_count == 1
 
 
+@pytest.mark.parametrize('gen', ['RGB', 'FFT'])
+def test_illustrip_depth_reparameterisation_vs_oracle(b32, gen):
+    """illustrip.py:385-409 with -d > 0: depth_transform (to_valid_rgb -> blur/lerp -> bicubic resize -> estimator x 2 -> merge ->
+    resize -> grid_warp, depth/depth.py:68-84) then frame_transform, then the new parameters -- FrameLoop.reparameterise on the HIP
+    kernels vs the oracle (depth_ref + restated affine + torch.fft).  The estimator is the same toy callable on both sides."""
+    from aphantasia_amd.illustrip_loop import FrameLoop
+    from oracle import depth_ref
+    h, w, S = 256, 320, 4
+    tgt = target512()
+    motion = dict(angle=1.0, shift=(4, -2), scale=1.02, shear=0.5)
+    seed_all(3)
+    p0 = torch.randn(1, 3, h, w) * 0.8 if gen == 'RGB' else 0.02 * torch.randn(1, 3, h, w // 2 + 1, 2)
+    kw = dict(sim='mix', transform=transforms.normalize(), rng='reference', lr=0.1, colors=1.5)
+    if gen == 'RGB':
+        kw.update(param_kind='pixel', rgb_priors=True)
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], **kw)
+    est = lambda image: depth_ref.toy_depth(image.cpu()).to(image.device)
+    loop = FrameLoop(eng, gen=gen, depth=0.3, depth_fn=est, colors=1.5, depth_res=126)
+    loop.reparameterise(motion['scale'], motion['shift'], motion['angle'], motion['shear'])
+    got = eng.params.detach().cpu().reshape(p0.shape)
+    if gen == 'RGB':
+        img = depth_ref.depth_transform(p0, depth_ref.toy_depth, 0.3, motion['scale'], motion['shift'], 1.5, res=126)
+        want = augment_ref.affine(img, motion['angle'], motion['shift'], motion['scale'], motion['shear'])
+    else:
+        img = torch.fft.irfftn(torch.view_as_complex(p0.contiguous()), s=(h, w), norm='ortho')
+        img = depth_ref.depth_transform(img, depth_ref.toy_depth, 0.3, motion['scale'], motion['shift'], 1.5, res=126)
+        img = augment_ref.affine(img, motion['angle'], motion['shift'], motion['scale'], motion['shear'])
+        want = torch.view_as_real(torch.fft.rfftn(img, s=(h, w), dim=[2, 3], norm='ortho')).contiguous()
+    assert (got - want).abs().max().item() < 2e-4 * want.abs().max().item(), (gen, (got - want).abs().max().item(), want.abs().max().item())
+    # and the loop still steps (finite loss, no skipped step) on the warped picture
+    seed_all(9)
+    loop.frame(**motion)
+    assert torch.isfinite(eng.loss).all() and int(eng.guard[0]) == 0
+    with pytest.raises(ValueError):
+        FrameLoop(eng, gen=gen, depth=0.3)            # depth without an estimator is refused, not ignored
+
+
 # ------------------------------------------------------------------------------------------------ CLI variants of the step
 @pytest.mark.parametrize('align', ['overscan', 'central', 'overmax'])
 def test_align_modes_step_vs_oracle(b32, align):

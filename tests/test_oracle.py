@@ -202,3 +202,17 @@ def test_augment_draw_semantics():
         if a['persp'] is not None:
             assert np.allclose(a['persp'], b['persp'], rtol=1e-5, atol=1e-7)
     assert sum(w['persp'] is not None for w in want) > 3 and sum(w['erase'] is not None for w in want) > 3
+
+
+def test_depthwarp_oracle_vs_reference_golden(golden):
+    """oracle/depth_ref.py == the reference's own depth/depth.py grid_warp / depthwarp / resize and utils.triangle_blur"""
+    from oracle import depth_ref as D
+    g = golden('depthwarp_40x56.npz')
+    t = lambda k: torch.from_numpy(g[k])
+    img_t, img, dep = t('img_t'), t('img'), t('dep')
+    assert torch.equal(D.grid_warp(img_t, dep, 40, 56, 0.3, [0.1, -0.2], 0.5), t('warp_a'))
+    assert torch.equal(D.grid_warp(img_t, dep, 40, 56, 4.0, [1.5, 0.7], 0.2, dlens=0.3), t('warp_b'))
+    assert torch.equal(D.triangle_blur(img, 5, 2), t('blur'))
+    assert torch.equal(D.resize(img, (28, 42)), t('resize_dn'))
+    assert torch.equal(D.resize(dep[None], (70, 75)), t('resize_up'))
+    assert torch.equal(D.depthwarp(img_t, img, D.toy_depth, 0.4, [0.2, -0.1], 0.6), t('depthwarp'))
