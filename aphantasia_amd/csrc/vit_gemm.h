@@ -53,6 +53,7 @@ struct GemmCfg {
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
+using GemmPair = GemmCfg<2, 2, 4, 4, 2>;     // 128 x 128, 256 threads (64x64 per wave), 64 KiB: TWO workgroups per CU, one in its epilogue while the other computes (experiment)
 
 template <class C>
 struct GemmFrags {
@@ -651,10 +652,15 @@ inline int& gemm_mfma32() {
 template <class C, class Epi>
 inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
   const dim3 grid((N / C::BN) * ((M + C::BM - 1) / C::BM));
-  if (gemm_mfma32()) {
-    APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false, true>), C::SMEM);
-    APH_LAUNCH((gemm_f16_kernel<C, Epi, false, true>), grid, dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, SplitK{nullptr, 1});
-  } else {
+  constexpr bool M32OK = C::TM % 2 == 0 && C::TN % 2 == 0 && C::EP_MT == C::TM;      // configurations the 32x32x16 variant exists for
+  if constexpr (M32OK) {
+    if (gemm_mfma32()) {
+      APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false, true>), C::SMEM);
+      APH_LAUNCH((gemm_f16_kernel<C, Epi, false, true>), grid, dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, SplitK{nullptr, 1});
+      return;
+    }
+  }
+  {
     APH_ALLOW_SMEM((gemm_f16_kernel<C, Epi, false, false>), C::SMEM);
     APH_LAUNCH((gemm_f16_kernel<C, Epi, false, false>), grid, dim3(C::NTHREAD), C::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, SplitK{nullptr, 1});
   }

@@ -94,6 +94,8 @@ def test_gemm_mfma_layout():
 def test_gemm_every_tile_config():
     for cfg in (1, 2, 4, 10):
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
+    K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64)], tile_cfg=11, variants=(0,))       # two workgroups per CU (2-stage ring)
+    K.check_gemm(None, DEV, [(9500, 3072, 768), (18715, 3072, 768)], tile_cfg=4, variants=(0,))   # persistent loop: 456 / 888 tiles on 256 CUs
 
 
 def test_gemm_splitk_matches_and_is_deterministic():
