@@ -51,6 +51,7 @@ _PROTOTYPES = {
     'aph_resize_bicubic': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'aph_flip_w': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_grid_warp': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'aph_attn_test': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'aph_frame_affine': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
     'aph_patchify_f16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_unpatchify_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),

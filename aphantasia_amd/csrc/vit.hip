@@ -150,43 +150,71 @@ void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const
 }
 
 // attention launches: T <= 64 one-tile kernels, 64 < T <= 256 the blocked kernels (NB = ceil(T / 64))
+struct AttnArgs {
+  const half_t* qkv; half_t* att; float* lse;        // forward: qkv -> att, lse
+  const half_t* datt; float* delta; half_t* dqkv;    // backward: (qkv, att, lse, datt) -> dqkv; delta [S*heads*T] scratch for T > 64
+  int S, T, heads;
+};
 template <int NB>
-void launch_attn_fwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+void launch_attn_fwd_g(const AttnArgs& a, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NB * 8192;
   APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem);
-  APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem, st, (const half_t*)l.qkv, l.att, l.lse, v->T, v->heads);
+  APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem, st, a.qkv, a.att, a.lse, a.T, a.heads);
 }
 template <int NB>
-void launch_attn_bwd_g(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+void launch_attn_bwd_g(const AttnArgs& a, hipStream_t st) {
   constexpr size_t smem_q = (size_t)3 * NB * 8192, smem_kv = (size_t)4 * NB * 8192 + 2 * NB * 64 * sizeof(float);
   APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q);
   APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv);
-  APH_LAUNCH((attn_bwd_dq_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_q, st, (const half_t*)l.qkv, (const half_t*)l.att,
-             (const half_t*)v->datt, (const float*)l.lse, v->delta, v->dqkv, v->T, v->heads);
-  APH_LAUNCH((attn_bwd_dkv_g_kernel<NB>), dim3(S * v->heads), dim3(512), smem_kv, st, (const half_t*)l.qkv, (const half_t*)v->datt,
-             (const float*)l.lse, (const float*)v->delta, v->dqkv, v->T, v->heads);
+  APH_LAUNCH((attn_bwd_dq_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem_q, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse, a.delta,
+             a.dqkv, a.T, a.heads);
+  APH_LAUNCH((attn_bwd_dkv_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem_kv, st, a.qkv, a.datt, (const float*)a.lse, (const float*)a.delta,
+             a.dqkv, a.T, a.heads);
 }
-void launch_attn_fwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
-  const int T = v->T;
-  if (T <= AT_T) APH_LAUNCH(attn_fwd_mfma_kernel, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, l.att, l.lse, T, v->heads);
-  else if (T <= 128) launch_attn_fwd_g<2>(v, l, S, st);
-  else if (T <= 192) launch_attn_fwd_g<3>(v, l, S, st);
-  else launch_attn_fwd_g<4>(v, l, S, st);
+void launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  const int T = a.T;
+  if (T <= AT_T) APH_LAUNCH(attn_fwd_mfma_kernel, dim3(a.S * a.heads), dim3(256), 0, st, a.qkv, a.att, a.lse, T, a.heads);
+  else if (T <= 128) launch_attn_fwd_g<2>(a, st);
+  else if (T <= 192) launch_attn_fwd_g<3>(a, st);
+  else launch_attn_fwd_g<4>(a, st);
 }
-void launch_attn_bwd(aph_vit* v, const Layer& l, int S, hipStream_t st) {
-  const int T = v->T;
+// workgroups of the persistent one-tile backward: 6 per CU (3 are resident at a time -- its LDS footprint; the second half starts as
+// the first finishes, which evens out the tail: measured 34.6 us one item per workgroup, 32.8 us with 3 per CU, 30.7 us with 6,
+// 31.8 with 8, 34.5 with 12 at C2, profiles/r02_attn_bwd_persistent.txt), never more than there are (cut, head) items
+inline int attn_bwd_wgs(int items) {
+#ifdef APH_EMU
+  return items < 3 ? items : 3;                     // exercises the item loop under the interpreter
+#else
+  static const int per_cu = [] { const char* e = getenv("APH_ATTN_BWD_WGS_PER_CU"); return e ? atoi(e) : 6; }();
+  if (per_cu <= 0) return items;                   // one item per workgroup (A/B runs)
+  thread_local int dev_cached = -1, ncu = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return items;
+  if (dev != dev_cached) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) return items;
+    dev_cached = dev;
+  }
+  const int w = ncu * per_cu;
+  return items < w ? items : w;
+#endif
+}
+void launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
+  const int T = a.T, items = a.S * a.heads;
   if (T <= AT_T)       // (the split dQ / dKdV kernels with NB = 1 were measured slower here: 7.62 vs 7.35 ms per C2 step)
   {
     if (T <= AT_RB)
-      APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
-                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse,
+                 a.dqkv, T, a.heads, items);
     else
-      APH_LAUNCH(attn_bwd_mfma_kernel<AT_T>, dim3(S * v->heads), dim3(256), 0, st, (const half_t*)l.qkv, (const half_t*)l.att,
-                 (const half_t*)v->datt, (const float*)l.lse, v->dqkv, T, v->heads);
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_T>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse,
+                 a.dqkv, T, a.heads, items);
   }
-  else if (T <= 128) launch_attn_bwd_g<2>(v, l, S, st);
-  else if (T <= 192) launch_attn_bwd_g<3>(v, l, S, st);
-  else launch_attn_bwd_g<4>(v, l, S, st);
+  else if (T <= 128) launch_attn_bwd_g<2>(a, st);
+  else if (T <= 192) launch_attn_bwd_g<3>(a, st);
+  else launch_attn_bwd_g<4>(a, st);
+}
+inline AttnArgs attn_args(aph_vit* v, const Layer& l, int S) {
+  return AttnArgs{(const half_t*)l.qkv, l.att, l.lse, (const half_t*)v->datt, v->delta, v->dqkv, S, v->T, v->heads};
 }
 
 }  // namespace
@@ -289,7 +317,7 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
     launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
     vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
-    launch_attn_fwd(v, l, S, st);
+    launch_attn_fwd(attn_args(v, l, S), st);
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
     // its attention runs on the S class rows alone: the same buffers addressed with a row pitch of T rows.
     const bool cls_only = li + 1 == v->L;
@@ -326,7 +354,7 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);
     vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
-    launch_attn_bwd(v, l, S, st);
+    launch_attn_bwd(attn_args(v, l, S), st);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
     launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
   }
@@ -377,6 +405,22 @@ int aph_gemm_set_mfma32(int on) {
   const int prev = gemm_mfma32();
   gemm_mfma32() = on ? 1 : 0;
   return prev;
+}
+
+// the attention kernels alone (unit tests, micro-benchmarks): mode 0 = forward (qkv -> att, lse), 1 = backward
+// ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16, att / datt [S*T, heads*64] f16, lse [S*heads*T] f32,
+// d_delta: S*heads*T floats of scratch, needed by the backward when T > 64.
+int aph_attn_test(const void* d_qkv, void* d_att, float* d_lse, const void* d_datt, float* d_delta, void* d_dqkv, int S, int T, int heads,
+                  int mode, void* stream_) {
+  APH_TRY
+  if (!d_qkv || !d_att || !d_lse || S < 1 || T < 1 || T > 256 || heads < 1 || (mode != 0 && mode != 1) ||
+      (mode == 1 && (!d_datt || !d_dqkv || (T > AT_T && !d_delta))))
+    return aph_fail(APH_ERR_ARG, "aph_attn_test: bad argument");
+  const AttnArgs a{(const half_t*)d_qkv, (half_t*)d_att, d_lse, (const half_t*)d_datt, d_delta, (half_t*)d_dqkv, S, T, heads};
+  if (mode == 0) launch_attn_fwd(a, (hipStream_t)stream_);
+  else launch_attn_bwd(a, (hipStream_t)stream_);
+  return aph_check_launch("aph_attn_test");
+  APH_CATCH
 }
 
 // plain C = A * Bt^T (f16 in, f32 out) -- exported for the GEMM unit tests and micro-benchmarks

@@ -28,17 +28,19 @@ __device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((
 // sc fastest.  An item loads the 8 rows whose slots form chunk sc (16 bytes each, rows >= T read as zero),
 // transposes the 8x8 block in registers and writes 8 + 8 full 16-byte chunks -- no scattered 2-byte LDS stores, no
 // separate zero fill, and the 8 lanes of a store group hit 8 different 16-byte slots of one 128-byte row.
-__device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, int ld, int T, int item, half_t* rowmajor,
-                                              half_t* transposed, int row_limit = 64) {
+__device__ __forceinline__ void at_stage_load(const half_t* __restrict__ src, int ld, int T, int item, half8 (&rows)[8]) {
   const int c = item >> 3, sc = item & 7;
   const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);          // rows n(sc, i) = nbase + (i >> 2) * 16 + (i & 3)
-  half8 rows[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n = nbase + ((i >> 2) << 4) + (i & 3);
     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     rows[i] = n < T ? *reinterpret_cast<const half8*>(src + (size_t)n * ld + c * 8) : z;
   }
+}
+__device__ __forceinline__ void at_stage_store(const half8 (&rows)[8], int item, half_t* rowmajor, half_t* transposed, int row_limit = 64) {
+  const int c = item >> 3, sc = item & 7;
+  const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);
   if (rowmajor) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -55,6 +57,12 @@ __device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, in
       *reinterpret_cast<half8*>(transposed + at_off(c * 8 + e, sc)) = col;
     }
   }
+}
+__device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, int ld, int T, int item, half_t* rowmajor,
+                                              half_t* transposed, int row_limit = 64) {
+  half8 rows[8];
+  at_stage_load(src, ld, T, item, rows);
+  at_stage_store(rows, item, rowmajor, transposed, row_limit);
 }
 
 __device__ __forceinline__ half8 at_frag(const half_t* tile, int row, int chunk) {
@@ -136,10 +144,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
 }
 
 // backward: (qkv, att, lse, datt) -> dqkv [M,3D] f16
+// PERSISTENT: the grid is a few workgroups per CU (3 fit its LDS), each walks the (cut, head) items with the grid stride.  The
+// operand rows of item i+1 are loaded into registers right after item i's have been written to LDS, so they are in flight
+// during item i's matrix products and stores: the kernel is HBM-bound (117 MB per launch at C2) and one item per workgroup
+// left the memory pipe idle during every compute phase (3.3 TB/s).
 template <int RB>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
+__global__ __launch_bounds__(256, 3) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
                                                            const half_t* __restrict__ datt, const float* __restrict__ lse,
-                                                           half_t* __restrict__ dqkv, int T, int heads) {
+                                                           half_t* __restrict__ dqkv, int T, int heads, int items) {
   constexpr int RT = RB * 64;                    // halfs per row-major tile
   __shared__ __attribute__((aligned(16))) half_t lds[4 * RT + 3 * 4096 + 256];
   half_t* Qs = lds;
@@ -151,39 +163,48 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
   half_t* Ot = Kt + 4096;         // dO transposed
   float* Ls = reinterpret_cast<float*>(Ot + 4096);
   float* Ds = Ls + 64;
-  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
   const int D = heads * 64, ld = 3 * D;
-  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
-  const half_t* dob = datt + (size_t)s * T * D + h * 64;
-  const half_t* ob = att + (size_t)s * T * D + h * 64;
-  {
-    const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
-    if (which == 0) at_stage_item(base, ld, T, item, Qs, Qt, RB);
-    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, Kt, RB);
-    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, Vs, nullptr, RB);
-    else at_stage_item(dob, D, T, item, Os, Ot, RB);
-  }
-  {
-    // D_i = dO_i . O_i : 4 threads per row
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-    float a = 0.f;
-    if (r < T) {
+  const int which = wave_uniform(threadIdx.x >> 6), sitem = threadIdx.x & 63;       // staging role: wave `which` stages Q / K / V / dO
+  const int dr = threadIdx.x >> 2, dpart = threadIdx.x & 3;           // D_i = dO_i . O_i : 4 threads per row
+  // prefetch registers of one item
+  half8 rows[8], ox[2], oy[2];
+  float lse_r = 0.f;
+  auto fetch = [&](int item) {
+    const int s = item / heads, h = item - s * heads;
+    const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+    const half_t* dob = datt + (size_t)s * T * D + h * 64;
+    const half_t* ob = att + (size_t)s * T * D + h * 64;
+    at_stage_load(which == 3 ? dob : base + which * D, which == 3 ? D : ld, T, sitem, rows);
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const half8 x = *reinterpret_cast<const half8*>(ob + (size_t)r * D + part * 16 + c * 8);
-        const half8 y = *reinterpret_cast<const half8*>(dob + (size_t)r * D + part * 16 + c * 8);
+    for (int c = 0; c < 2; ++c) {
+      ox[c] = dr < T ? *reinterpret_cast<const half8*>(ob + (size_t)dr * D + dpart * 16 + c * 8) : z;
+      oy[c] = dr < T ? *reinterpret_cast<const half8*>(dob + (size_t)dr * D + dpart * 16 + c * 8) : z;
+    }
+    lse_r = (dpart == 0 && dr < T) ? lse[((size_t)s * heads + h) * T + dr] : 0.f;
+  };
+  int item = blockIdx.x;
+  fetch(item);
+  for (;;) {
+    const int s = item / heads, h = item - s * heads;
+    // wave `which` = Q, K, V, dO: row-major tile `which`; transposed image for Q (0), K (1), dO (2) -- V has none
+    at_stage_store(rows, sitem, lds + which * RT, which == 2 ? nullptr : lds + 4 * RT + (which == 3 ? 2 : which) * 4096, RB);
+    {
+      float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a += (float)x[e] * (float)y[e];
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)ox[c][e] * (float)oy[c][e];
+      a += __shfl_xor(a, 1);
+      a += __shfl_xor(a, 2);
+      if (dpart == 0) {
+        Ds[dr] = a;
+        Ls[dr] = lse_r;
       }
     }
-    a += __shfl_xor(a, 1);
-    a += __shfl_xor(a, 2);
-    if (part == 0) {
-      Ds[r] = a;
-      Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] : 0.f;
-    }
-  }
-  __syncthreads();
+    __syncthreads();
+    const int next = item + gridDim.x;
+    if (next < items) fetch(next);               // in flight during the products and stores below
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
   half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
   if (w * 16 < T) {
@@ -257,6 +278,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const half_t* __rest
         store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[0], ov[1], ov[2], ov[3]);
       }
     }
+  }
+    if (next >= items) break;
+    item = next;
+    __syncthreads();                             // every wave is done with this item's LDS image
   }
 }
 

@@ -14,6 +14,11 @@ extern "C" {
 /* per-launch HIP-event timing of the ViT's GEMM launches (bench.py roofline): on/off, then read the sums */
 int aph_vit_profile(aph_vit* vit, int on);
 int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
+/* The ViT's attention kernels alone (head dim 64, T <= 256): mode 0 = forward (qkv -> att, lse), mode 1 = backward
+ * ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16 (q | k | v column blocks), att / datt [S*T, heads*64] f16,
+ * lse [S*heads*T] f32 (log-sum-exp of the scores / 8); d_delta: S*heads*T floats of scratch for the backward when T > 64. */
+int aph_attn_test(const void* d_qkv, void* d_att, float* d_lse, const void* d_datt, float* d_delta, void* d_dqkv, int S, int T, int heads,
+                  int mode, void* stream);
 /* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core with the automatic tile choice */
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
 /* same with explicit row pitches (elements, multiples of 8) and an explicit tile configuration:

@@ -482,3 +482,39 @@ def check_depthwarp(lib, dev, g, sizes=((40, 56), (37, 51), (64, 48))):
     x = torch.randn(1, 3, 33, 47, generator=gen)
     got = DW.grid_warp(x.to(dev), torch.rand(1, 33, 47, generator=gen).to(dev), 33, 47, 0.0, [0.4, 0.1], 0.5, lib=lib).cpu()
     assert (got - x).abs().max().item() < 2e-5
+
+
+def attention_ref(qkv, S, T, heads):
+    """plain torch fp32 multi-head attention on the packed [S*T, 3*heads*64] activations (clip/model.py's nn.MultiheadAttention core:
+    softmax(q k^T / sqrt(64)) v per head); returns att [S*T, heads*64] and the log-sum-exp of the scaled scores [S, heads, T]"""
+    D = heads * 64
+    x = qkv.float().reshape(S, T, 3, heads, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))            # [S, heads, T, 64]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    att = torch.softmax(sc, dim=-1) @ v
+    return att.permute(0, 2, 1, 3).reshape(S * T, D), torch.logsumexp(sc, dim=-1)
+
+
+def check_attention(lib, dev, S, T, heads, seed=0):
+    """the attention kernels alone (aph_attn_test) vs torch fp32 autograd on the same f16-rounded inputs"""
+    L = lib if lib is not None else _ffi.lib()
+    g = torch.Generator().manual_seed(seed)
+    D = heads * 64
+    qkv = (torch.randn(S * T, 3 * D, generator=g) * 1.5).half()
+    datt = torch.randn(S * T, D, generator=g).half()
+    ref_in = qkv.float().requires_grad_(True)
+    want_att, want_lse = attention_ref(ref_in, S, T, heads)
+    (want_att * datt.float()).sum().backward()
+    q_d, d_d = qkv.to(dev).contiguous(), datt.to(dev).contiguous()
+    att = torch.empty(S * T, D, dtype=torch.float16, device=dev)
+    lse = torch.empty(S * heads * T, dtype=torch.float32, device=dev)
+    dqkv = torch.zeros(S * T, 3 * D, dtype=torch.float16, device=dev)
+    delta = torch.empty(S * heads * T, dtype=torch.float32, device=dev)
+    st = ops._stream(q_d)
+    L.call('aph_attn_test', ops.ptr(q_d), ops.ptr(att), ops.ptr(lse), None, None, None, S, T, heads, 0, st)
+    assert (att.float().cpu() - want_att.detach()).abs().max().item() < 4e-3 * want_att.abs().max().item()
+    assert (lse.cpu().reshape(S, heads, T) - want_lse.detach()).abs().max().item() < 2e-3
+    L.call('aph_attn_test', ops.ptr(q_d), ops.ptr(att), ops.ptr(lse), ops.ptr(d_d), ops.ptr(delta), ops.ptr(dqkv), S, T, heads, 1, st)
+    err = (dqkv.float().cpu() - ref_in.grad).abs().max().item()
+    assert err < 8e-3 * ref_in.grad.abs().max().item(), (S, T, heads, err, ref_in.grad.abs().max().item())
+    return att, dqkv

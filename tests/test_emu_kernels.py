@@ -124,3 +124,9 @@ def test_adam_guard(emu):
 
 def test_depthwarp(emu, golden):
     K.check_depthwarp(emu, 'cpu', golden('depthwarp_40x56.npz'), sizes=((37, 51),))
+
+
+def test_attention_alone(emu):
+    K.check_attention(emu, 'cpu', S=5, T=50, heads=2)       # 10 (cut, head) items on 3 persistent workgroups: 4 / 3 / 3 items each
+    K.check_attention(emu, 'cpu', S=1, T=60, heads=1)       # one item, 64-row tiles
+    K.check_attention(emu, 'cpu', S=2, T=82, heads=1)       # blocked kernels (T > 64)

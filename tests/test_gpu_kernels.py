@@ -87,6 +87,22 @@ def test_adam():
     K.check_adam(None, DEV, n=2769120)
 
 
+def test_attention_alone_vs_torch():
+    """attention forward / backward kernels through the test hook: ViT-B/32 (T = 50, full batch of 190 cuts x 12 heads: the persistent
+    backward's item loop), T = 64 tiles, ViT-B/16 (T = 197) and the sizes in between"""
+    K.check_attention(None, DEV, S=190, T=50, heads=12)
+    K.check_attention(None, DEV, S=7, T=50, heads=12)
+    for T in (17, 56, 57, 64, 82, 145, 197):
+        K.check_attention(None, DEV, S=3, T=T, heads=12, seed=T)
+
+
+def test_attention_backward_is_deterministic():
+    import torch
+    a1, d1 = K.check_attention(None, DEV, S=190, T=50, heads=12)
+    a2, d2 = K.check_attention(None, DEV, S=190, T=50, heads=12)
+    assert torch.equal(a1, a2) and torch.equal(d1, d2)
+
+
 def test_gemm_mfma_layout():
     K.check_gemm(None, DEV, [(100, 128, 64), (130, 256, 192), (9500, 768, 768), (1000, 3072, 768), (777, 768, 3072)])
 
