@@ -1,7 +1,8 @@
 """The multi-GPU collective: one all-reduce of the parameter gradient per step, RCCL called
 directly through the C ABI (aph_comm_* in csrc/comm.hip).  One process per GPU; the 128-byte RCCL unique id is the only
 thing that travels out of band -- through an already-initialised torch.distributed group when there is one (bench.py under
-torchrun: a one-off control-plane broadcast), else through a rendezvous file (clip_fft.py --ranks).
+torchrun: a one-off control-plane broadcast), through a rendezvous file keyed by the launch (clip_fft.py --ranks spawns the
+ranks itself), or through a throw-away gloo group on torchrun's rendezvous (torchrun + clip_fft.py).
 """
 import ctypes
 import os
@@ -48,8 +49,10 @@ def new_unique_id(lib=None):
     return bytes(buf)
 
 
-def _file_exchange(rank, world, uid, key, timeout=120.0):
-    """rank 0 publishes the id in a rendezvous file, the others wait for it (all ranks share one node's /tmp)"""
+def _file_exchange(rank, world, uid, key, timeout=300.0):
+    """rank 0 publishes the id in a rendezvous file, the others wait for it (all ranks share one node's /tmp).  `key` must be
+    unique to this launch (clip_fft.py --ranks passes parent pid + a random port): no freshness heuristics, a slow importer
+    simply finds the file already there."""
     path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'aph_rccl_uid_%s' % key)
     if rank == 0:
         tmp = path + '.%d' % os.getpid()
@@ -59,14 +62,24 @@ def _file_exchange(rank, world, uid, key, timeout=120.0):
         return uid
     t0 = time.time()
     while time.time() - t0 < timeout:
-        if os.path.isfile(path) and os.path.getsize(path) == 128 and os.path.getmtime(path) >= _START - 2.0:
+        if os.path.isfile(path) and os.path.getsize(path) == 128:
             with open(path, 'rb') as f:
                 return f.read()
         time.sleep(0.02)
     raise RuntimeError('no RCCL unique id at %s after %.0f s (is rank 0 running with the same rendezvous key?)' % (path, timeout))
 
 
-_START = time.time()
+def _gloo_exchange(rank, world, uid):
+    """torchrun without a process group of the caller's: a throw-away gloo group on torchrun's own rendezvous (env://) carries
+    the 128 bytes; nothing of it survives this call"""
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        t = torch.tensor(list(uid), dtype=torch.uint8) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
+        dist.broadcast(t, src=0)
+        return bytes(t.tolist())
+    finally:
+        dist.destroy_process_group()
 
 
 def create(rank, world, device=None, lib=None, key=None):
@@ -80,7 +93,11 @@ def create(rank, world, device=None, lib=None, key=None):
         t = torch.tensor(list(uid), dtype=torch.uint8, device=dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)                    # one-off control-plane exchange of 128 bytes
         uid = bytes(t.cpu().tolist())
+    elif key is not None or 'APH_RUN_ID' in os.environ:
+        uid = _file_exchange(rank, world, uid, key or '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ['APH_RUN_ID']))
+    elif dist.is_available() and all(k in os.environ for k in ('MASTER_ADDR', 'MASTER_PORT', 'RANK', 'WORLD_SIZE')):
+        uid = _gloo_exchange(rank, world, uid)
     else:
-        key = key or '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', os.environ.get('APH_RUN_ID', 'x')))
-        uid = _file_exchange(rank, world, uid, key)
+        raise RuntimeError('comm.create: no way to hand the RCCL unique id to the other ranks (no torch.distributed group, no APH_RUN_ID '
+                           'rendezvous key, no torchrun environment)')
     return Comm(rank, world, uid, lib)

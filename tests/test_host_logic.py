@@ -188,3 +188,32 @@ def test_error_convention_on_bad_arguments(product_lib):
         rc = call()
         assert rc < 0, name
         assert product_lib.last_error(), name
+
+
+def _uid_worker(rank, world, port, mode, q):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from aphantasia_amd import comm as acomm
+    uid = bytes(range(128)) if rank == 0 else None
+    if mode == 'file':
+        got = acomm._file_exchange(rank, world, uid, 'test_%d' % port, timeout=60.0)
+    else:
+        got = acomm._gloo_exchange(rank, world, uid)
+    q.put((rank, got))
+
+
+@pytest.mark.parametrize('mode', ['file', 'gloo'])
+def test_rccl_unique_id_exchange_two_processes(mode):
+    """the two out-of-band paths that carry the 128-byte RCCL id when the caller has no torch.distributed group
+    (comm.create: clip_fft.py --ranks -> rendezvous file keyed by the launch; torchrun + clip_fft.py -> throw-away gloo group)"""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + (7 if mode == 'gloo' else 0)
+    procs = [ctx.Process(target=_uid_worker, args=(r, 2, port, mode, q)) for r in (1, 0)]        # the reader starts first
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res[0] == bytes(range(128)) and res[1] == bytes(range(128))
