@@ -400,7 +400,7 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
   APH_CATCH
 }
 
-// MFMA shape of every GEMM main loop launched from now on: 1 = 32x32x16 (default), 0 = 16x16x32.  Returns the previous value.
+// MFMA shape of every GEMM main loop launched from now on: 0 = 16x16x32 (default), 1 = 32x32x16.  Returns the previous value.
 int aph_gemm_set_mfma32(int on) {
   const int prev = gemm_mfma32();
   gemm_mfma32() = on ? 1 : 0;
