@@ -251,7 +251,7 @@ def txt_clean(txt):
 def checkout(img, fname=None, verbose=False):
     """utils.py:94-100: CHW float image in [0,1] -> uint8 JPEG on disk"""
     from PIL import Image
-    arr = np.transpose(np.array(img)[:, :, :], (1, 2, 0))
+    arr = np.transpose(img.detach().cpu().numpy() if torch.is_tensor(img) else np.array(img), (1, 2, 0))
     arr = np.clip(arr * 255, 0, 255).astype(np.uint8)
     if fname is not None:
         Image.fromarray(arr).save(fname, quality=95)

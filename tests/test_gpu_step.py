@@ -425,3 +425,28 @@ def test_loss_scale_backs_off_after_fp16_overflow(model):
     assert eng.loss_scale < 2.0 ** 30 and int(eng.guard[0]) > 0
     assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, p0)
     assert last < first - 0.02, (first, last, eng.loss_scale)
+
+
+@pytest.mark.parametrize('gen', ['RGB', 'FFT'])
+def test_illustrip_cli_frames_with_and_without_depth(tmp_path, monkeypatch, gen):
+    """illustrip.py end to end (synthetic CLIP weights): frames on disk, no skipped steps; `-d` runs the depth warp with a stand-in
+    estimator (the CLI's own InferDepthAny needs a local Depth-Anything checkpoint and must refuse to start without one)"""
+    import illustrip
+    from aphantasia_amd import depthwarp
+    from oracle import depth_ref
+    out = str(tmp_path / 'o')
+    base = ['-t', 'a cat', '-nv', '--seed', '0', '--steps', '3', '--samples', '12', '--size', '320-256', '--gen', gen, '--out_dir', out]
+    illustrip.main(base)
+    frames = [f for d, _, fs in os.walk(out) for f in fs if f.endswith('.jpg')]
+    assert len(frames) == 3
+    with pytest.raises(RuntimeError, match='Depth-Anything'):
+        illustrip.main(base + ['-d', '0.3'])
+
+    class ToyDepth:
+        def __init__(self, *a, **k): pass
+        def __call__(self, image): return depth_ref.toy_depth(image.cpu()).to(image.device)
+    monkeypatch.setattr(depthwarp, 'InferDepthAny', ToyDepth)
+    out2 = str(tmp_path / 'o2')
+    illustrip.main(base[:-1] + [out2, '-d', '0.3', '--depth_dir', str(tmp_path / 'dm')])
+    assert len([f for d, _, fs in os.walk(out2) for f in fs if f.endswith('.jpg')]) == 3
+    assert len(os.listdir(str(tmp_path / 'dm'))) == 3              # one depth map per frame (depth.py:80-82)
