@@ -74,6 +74,7 @@ def get_args(argv=None):
     p.add_argument('--seed', default=None, type=int)
     p.add_argument('--no_save', action='store_true')
     p.add_argument('--rng', default=None, choices=['bulk', 'reference'])
+    p.add_argument('--ranks', default=1, type=int, help='GPUs of this node to shard the cuts over (launch with torchrun, or let this flag spawn the ranks)')
     a = p.parse_args(argv)
     a.size = [int(s) for s in a.size.split('-')][::-1]                    # illustrip.py:90-91
     if len(a.size) == 1: a.size = a.size * 2
@@ -102,8 +103,34 @@ def derate_samples(a):
     return s
 
 
+def _spawn_rank(local_rank, argv, world, port, run_id):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), APH_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    main(argv)
+
+
 def main(argv=None):
     a = get_args(argv)
+    # multi-GPU as clip_fft.py: every rank holds the same picture, draws the same crop tables (same seed) and takes its share of the
+    # cuts; one RCCL all-reduce of the parameter gradient per step.  The per-frame warp / re-parameterisation is replicated.
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if a.ranks > 1 and 'RANK' not in os.environ:
+        import torch.multiprocessing as mp
+        args = list(sys.argv[1:] if argv is None else argv)
+        if a.seed is None:
+            args += ['--seed', str(int.from_bytes(os.urandom(3), 'little'))]
+        port = 20000 + int.from_bytes(os.urandom(2), 'little') % 20000
+        mp.spawn(_spawn_rank, args=(args, a.ranks, port, 'i%d' % os.getpid()), nprocs=a.ranks, join=True)
+        return
+    comm = None
+    if world > 1:
+        if a.seed is None:
+            raise SystemExit(' multi-rank runs need --seed (every rank draws the same crop / augment tables and takes its share of the cuts)')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+        from aphantasia_amd import comm as acomm
+        comm = acomm.create(rank, world)
+        if rank != 0:
+            a.verbose, a.no_save, a.depth_dir = False, True, None            # rank 0 reports and writes the frames / depth maps
     if a.aest != 0 or a.transform in ('custom', 'elastic'):
         raise SystemExit(' --aest / -tf custom|elastic are not part of this path')
     if a.in_txt is None and a.in_txt2 is None:
@@ -145,7 +172,7 @@ def main(argv=None):
         leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).cuda().contiguous()
         pk = dict(param_kind='fft', decay=1.0)                                                  # fft_image default decay_power (illustrip.py:409)
     kw = dict(sim=a.sim, colors=a.colors, lr=a.lrate, optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trf, sharp=a.sharp,
-              expand=a.expand, enforce=a.enforce, rng=a.rng, **pk)
+              expand=a.expand, enforce=a.enforce, rng=a.rng, rank=rank, world=world, comm=comm, **pk)
     eng = Engine(leaf, h, w, model, S, targets_for(model), **kw)
     eng2 = Engine(leaf, h, w, model2, S, targets_for(model2), state=eng.state(), **kw) if model2 is not None else None
     depth_fn = None
@@ -166,14 +193,17 @@ def main(argv=None):
                          noise=a.noise if a.gen == 'FFT' else 0.0)
         if writer is not None:
             writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%06d.jpg' % num), 1.0)
-        if a.verbose and (num % 10 == 9 or num == a.steps - 1):
-            print(' frame %d/%d  loss %.4f  %.1f frames/s' % (num + 1, a.steps, float(eng.loss), (num + 1) / (time.time() - t0)), flush=True)
+        if (a.verbose or world > 1) and (num % 10 == 9 or num == a.steps - 1):
+            gl = eng.global_loss()             # (a collective when world > 1: every rank takes part, rank 0 prints)
+            if a.verbose:
+                print(' frame %d/%d  loss %.4f  %.1f frames/s' % (num + 1, a.steps, gl, (num + 1) / (time.time() - t0)), flush=True)
     torch.cuda.synchronize()
     if writer is not None:
         writer.close()
         if shutil.which('ffmpeg'):
             os.system('ffmpeg -v warning -y -i %s/\\%%06d.jpg "%s.mp4"' % (tempdir, os.path.join(a.out_dir, name)))
-    print(' done: %d frames in %.1fs (%.1f frames/s)' % (a.steps, time.time() - t0, a.steps / (time.time() - t0)))
+    if rank == 0:
+        print(' done: %d frames in %.1fs (%.1f frames/s)%s' % (a.steps, time.time() - t0, a.steps / (time.time() - t0), ' on %d ranks' % world if world > 1 else ''))
 
 
 if __name__ == '__main__':
