@@ -53,6 +53,7 @@ struct GemmCfg {
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
+using GemmFat = GemmCfg<2, 2, 8, 4, 3>;      // 256 x 128, 256 threads: FOUR waves of 128x64 (one per SIMD): half the LDS fragment bytes per flop of GemmBig (experiment)
 using GemmPair = GemmCfg<2, 2, 4, 4, 2>;     // 128 x 128, 256 threads (64x64 per wave), 64 KiB: TWO workgroups per CU, one in its epilogue while the other computes (experiment)
 
 template <class C>

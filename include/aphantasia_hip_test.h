@@ -26,6 +26,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *    1  64x64, 4 waves            2  256x128, 8 waves, 3-stage ring       4  256x256 phased (needs N % 256 == 0)
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
+ *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
  *   22 / 24  128x128 split-K x2 / x4
  * any other value is rejected (APH_ERR_ARG). */
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
