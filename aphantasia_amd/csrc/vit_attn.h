@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
 // during item i's matrix products and stores: the kernel is HBM-bound (117 MB per launch at C2) and one item per workgroup
 // left the memory pipe idle during every compute phase (3.3 TB/s).
 template <int RB>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
-__global__ __launch_bounds__(256, 3) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
+__global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
                                                            const half_t* __restrict__ datt, const float* __restrict__ lse,
                                                            half_t* __restrict__ dqkv, int T, int heads, int items) {
   constexpr int RT = RB * 64;                    // halfs per row-major tile

@@ -84,6 +84,13 @@ __device__ __forceinline__ void ring_wait(int ahead) {
   else wait_vm_barrier<2 * C::GPT>();
 }
 
+__device__ __forceinline__ void mfma_prio(int on) {
+#ifndef APH_EMU
+  if (on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+  else { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+#endif
+}
+
 // Split-K (latency-bound shapes: small M, long K): `splits` workgroups share one output tile, each running a contiguous
 // share of the k-tiles and writing its fp32 partial tile to ws[split][M][N]; a second small kernel sums the partials in
 // split order 0..splits-1 (fixed order: bitwise reproducible) and applies the epilogue.  The kernel boundary is the
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(C::NTHREAD) void gemm_f16_kernel(const half_t* __re
     if constexpr (M32) gemm_load_frags32<C>(g1, As_, As_ + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
     else gemm_load_frags<C>(f1, As_, As_ + C::BM * GEMM_BK, arow, brow, 4 + fchunk);
   };
+  // (s_setprio around these MFMA clusters was measured: no change on any ViT shape -- the two waves of a SIMD already alternate)
   auto mma0 = [&]() { if constexpr (M32) gemm_mma32<C>(acc32, g0); else gemm_mma<C>(acc, f0); };
   auto mma1 = [&]() { if constexpr (M32) gemm_mma32<C>(acc32, g1); else gemm_mma<C>(acc, f1); };
 #pragma unroll
@@ -318,12 +326,6 @@ __device__ __forceinline__ void phase_barrier(bool wait, bool last) {
   if (!wait) wait_vm_barrier<63>();
   else if (last) wait_vm_barrier<0>();
   else wait_vm_barrier<4>();
-}
-__device__ __forceinline__ void mfma_prio(int on) {
-#ifndef APH_EMU
-  if (on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
-  else { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
-#endif
 }
 
 template <class Epi, bool M32 = false>
