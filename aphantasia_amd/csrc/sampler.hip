@@ -75,6 +75,12 @@ __device__ __forceinline__ float gload(const void* __restrict__ g, size_t o) {
 }
 template <int OUT>
 struct is_patch { static constexpr bool v = OUT == APH_OUT_PATCH_F16 || OUT == APH_GRAD_PATCH_F16; };
+// internal layout of the per-cut scratch of the FORWARD augment chain (never crosses the C ABI): f32 [S][size][size][4] = (r, g, b, pad).
+// Every bilinear tap of the perspective / rotation warps is then ONE 16-byte access for the three channels instead of three 4-byte
+// ones in three planes (the warps are bound by L1 line accesses: crop + persp + rotate 311 -> 280 us at C2).  The ADJOINT chain keeps
+// planar [S][3][size][size] scratch: its gathers are bound by L2 / fabric bytes, and the pad lane made it slower (566 -> 594 us).
+constexpr int APH_SCRATCH_HWC4 = 8;
+__device__ __forceinline__ size_t hwc4_index(int s, int i, int j, int size) { return (((size_t)s * size + i) * size + j) * 4; }
 
 // gradient w.r.t. the un-normalised cut pixel (c,i,j) of cut s, read from `gout` in layout OUT
 template <int OUT>
@@ -99,7 +105,9 @@ __device__ __forceinline__ void fetch_grad3(const void* __restrict__ gout, int s
 }
 template <int OUT>
 __device__ __forceinline__ void emit3(void* out, int s, int i, int j, int size, int patch, float v0, float v1, float v2) {
-  if (OUT == APH_OUT_PATCH_F16) {
+  if (OUT == APH_SCRATCH_HWC4) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + hwc4_index(s, i, j, size)) = f32x4{v0, v1, v2, 0.f};
+  } else if (OUT == APH_OUT_PATCH_F16) {
     const size_t o = patch_index(s, 0, i, j, size, patch);
     const int pp = patch * patch;
     half_t* q = reinterpret_cast<half_t*>(out);
@@ -471,11 +479,13 @@ __device__ __forceinline__ bool in_rect(const float* __restrict__ a, int y, int 
   return y >= ei && y < ei + eh && x >= ej && x < ej + ew;
 }
 
-// sampled value times sampled ones-mask (fill = 0); ERASE: source pixels inside the erase rectangle read as 0
+// sampled value (three channels of one HWC4 cut image) times sampled ones-mask (fill = 0); ERASE: source pixels inside the
+// erase rectangle read as 0
 template <bool ERASE>
-__device__ __forceinline__ float warp_gather(const float* __restrict__ src, const Tap& t, int n, const float* __restrict__ a) {
-  // branch-free: out-of-range taps read a clamped address with weight 0, so the four loads issue together
-  float v = 0.f, m = 0.f;
+__device__ __forceinline__ void warp_gather3(const float* __restrict__ src, const Tap& t, int n, const float* __restrict__ a, float v[3]) {
+  // branch-free: out-of-range taps read a clamped address with weight 0, so the four 16-byte loads issue together
+  float m = 0.f;
+  v[0] = v[1] = v[2] = 0.f;
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -484,26 +494,25 @@ __device__ __forceinline__ float warp_gather(const float* __restrict__ src, cons
       const bool in = yy >= 0 && yy < n && xx >= 0 && xx < n;
       const float w = in ? (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0) : 0.f;
       const int yc = yy < 0 ? 0 : (yy > n - 1 ? n - 1 : yy), xc = xx < 0 ? 0 : (xx > n - 1 ? n - 1 : xx);
-      const float sv = src[(size_t)yc * n + xc];
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(src + ((size_t)yc * n + xc) * 4);
       m += w;
-      v += (ERASE && in_rect(a, yc, xc)) ? 0.f : w * sv;
+      const float we = (ERASE && in_rect(a, yc, xc)) ? 0.f : w;
+      v[0] += we * sv[0]; v[1] += we * sv[1]; v[2] += we * sv[2];
     }
-  return v * m;
+  v[0] *= m; v[1] *= m; v[2] *= m;
 }
 
-// stage 1: RandomPerspective for the cuts that drew it (A -> B); other cuts are skipped
+// stage 1: RandomPerspective for the cuts that drew it (A -> B, both HWC4); other cuts are skipped
 __global__ void persp_kernel(const float* __restrict__ A, const float* __restrict__ aug, float* __restrict__ Bo, int n) {
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= n || j >= n) return;
-  const int pix = i * n + j;
   const Tap t = persp_tap(a, i, j, n);
-  for (int c = 0; c < 3; ++c) {
-    const size_t pl = ((size_t)s * 3 + c) * n * n;
-    Bo[pl + pix] = warp_gather<false>(A + pl, t, n, a);
-  }
+  float v[3];
+  warp_gather3<false>(A + hwc4_index(s, 0, 0, n), t, n, a, v);
+  *reinterpret_cast<f32x4*>(Bo + hwc4_index(s, i, j, n)) = f32x4{v[0], v[1], v[2], 0.f};
 }
 
 // stage 2: RandomErasing (read-side) + rotation + normalise + emit
@@ -514,18 +523,17 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= n || j >= n) return;
-  const int pix = i * n + j;
-  const float* src = a[8] != 0.f ? Bi : A;
+  const float* src = (a[8] != 0.f ? Bi : A) + hwc4_index(s, 0, 0, n);
+  float v[3];
   if (a[15] != 0.f) {
     const Tap t = rot_tap(a[13], a[14], i, j, n);
-    float v[3];
-    for (int c = 0; c < 3; ++c) v[c] = warp_gather<true>(src + ((size_t)s * 3 + c) * n * n, t, n, a);
-    emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
+    warp_gather3<true>(src, t, n, a, v);
   } else {
-    float v[3];
-    for (int c = 0; c < 3; ++c) v[c] = in_rect(a, i, j) ? 0.f : src[((size_t)s * 3 + c) * n * n + pix];
-    emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(src + ((size_t)i * n + j) * 4);
+    const bool er = in_rect(a, i, j);
+    v[0] = er ? 0.f : q[0]; v[1] = er ? 0.f : q[1]; v[2] = er ? 0.f : q[2];
   }
+  emit3<OUT>(out, s, i, j, n, patch, v[0], v[1], v[2]);
 }
 
 // sum of the in-bounds bilinear weights (= the sampled ones-mask of torchvision's fill handling)
@@ -552,7 +560,6 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (py >= n || px >= n) return;
-  const int pix = py * n + px;
   float* dst = a[8] != 0.f ? dB : dA;
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   if (!in_rect(a, py, px)) {
@@ -607,7 +614,7 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
       g0 = gq[0]; g1 = gq[1]; g2 = gq[2];
     }
   }
-  const size_t pl = (size_t)s * 3 * n * n;
+  const size_t pl = (size_t)s * 3 * n * n, pix = (size_t)py * n + px;
   dst[pl + pix] = g0;
   dst[pl + (size_t)n * n + pix] = g1;
   dst[pl + 2 * (size_t)n * n + pix] = g2;
@@ -621,8 +628,7 @@ __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* 
   if (a[8] == 0.f) return;
   const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (py >= n || px >= n) return;
-  const int pix = py * n + px;
-  // forward: (u, v) = H (x, y), x = j + .5, y = i + .5, source index = (u - .5, v - .5);  adj(H) maps back
+    // forward: (u, v) = H (x, y), x = j + .5, y = i + .5, source index = (u - .5, v - .5);  adj(H) maps back
   const float m00 = a[4] - a[5] * a[7], m01 = a[2] * a[7] - a[1], m02 = a[1] * a[5] - a[2] * a[4];
   const float m10 = a[5] * a[6] - a[3], m11 = a[0] - a[2] * a[6], m12 = a[2] * a[3] - a[0] * a[5];
   const float m20 = a[3] * a[7] - a[4] * a[6], m21 = a[1] * a[6] - a[0] * a[7], m22 = a[0] * a[4] - a[1] * a[3];
@@ -650,6 +656,7 @@ __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* 
       g1 += wm * dB[o + nn];
       g2 += wm * dB[o + 2 * nn];
     }
+  const size_t pix = (size_t)py * n + px;
   dA[pl + pix] = g0;
   dA[pl + nn + pix] = g1;
   dA[pl + 2 * nn + pix] = g2;
@@ -736,7 +743,7 @@ size_t tab_bytes(const Geom& g) {
   const size_t maxcs = (size_t)(g.Hp < g.Wp ? g.Hp : g.Wp);    // a cut fits the (padded) image; csize <= min(H, W) upstream (utils.py:231,245)
   return ((size_t)g.S * 2 * maxcs * sizeof(AdjEntry) + 255) & ~(size_t)255;
 }
-size_t scratch_floats(const Geom& g) { return (size_t)g.S * 3 * g.size * g.size; }
+size_t scratch_floats(const Geom& g) { return (size_t)g.S * 4 * g.size * g.size; }     // HWC4 in the forward; the adjoint uses 3/4 of it, planar
 // per-XCD unit lists of the forward: [8][cap] + [8] ints
 int strip_cap(const Geom& g) { return g.S * ((g.size + 3) / 4); }
 size_t strip_bytes(const Geom& g) { return ((size_t)(8 * (size_t)strip_cap(g) + 8) * sizeof(int) + 255) & ~(size_t)255; }
@@ -786,7 +793,7 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g) + strip_bytes(g));
   float* Bv = A + scratch_floats(g);
   // resized cut -> A; RandomPerspective for the cuts that drew it A -> B; RandomErasing + rotation + normalise (A or B) -> out
-  launch_crop_resize<APH_OUT_NCHW_RAW>(rgb, (const int*)table, (void*)A, g, ws, st);
+  launch_crop_resize<APH_SCRATCH_HWC4>(rgb, (const int*)table, (void*)A, g, ws, st);
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
