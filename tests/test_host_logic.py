@@ -99,6 +99,11 @@ def test_alias_package_exposes_reference_names():
     for n in ('slice_imgs', 'sim_func', 'pad_up_to'):
         assert callable(getattr(ut, n))
     assert callable(tr.normalize) and tr.transforms_fast is not None
+    import depth.depth as dd                                   # illustrip.py:30 `from depth import depth`
+    for n in ('grid_warp', 'depthwarp', 'resize', 'InferDepthAny'):
+        assert callable(getattr(dd, n))
+    with pytest.raises(RuntimeError, match='Depth-Anything'):
+        dd.InferDepthAny('b', path=None)                       # no checkpoint: refuse, do not invent a depth map
 
 
 def test_resume_from_image_helpers_match_reference_golden(tmp_path):
@@ -183,6 +188,13 @@ def test_error_convention_on_bad_arguments(product_lib):
         'aph_rgb_sharp': lambda: L.aph_rgb_sharp(null, 4, 4, ctypes.c_float(1.0), null, null, null, null),
         'aph_frame_affine': lambda: L.aph_frame_affine(null, 3, 4, 4, null, null, null),
         'aph_gemm_f16': lambda: L.aph_gemm_f16(null, null, 1, 128, 64, null, null),
+        'aph_triangle_blur': lambda: L.aph_triangle_blur(null, 3, 8, 8, 5, ctypes.c_float(2.0), ctypes.c_float(0.5), null, null),
+        'aph_resize_bicubic': lambda: L.aph_resize_bicubic(null, 3, 8, 8, null, 4, 4, null),
+        'aph_flip_w': lambda: L.aph_flip_w(null, null, 3, 8, 8, null, null),
+        'aph_grid_warp': lambda: L.aph_grid_warp(null, null, 3, 8, 8, ctypes.c_float(0.3), ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.5),
+                                                 ctypes.c_float(0.05), null, null, null),
+        'aph_attn_test': lambda: L.aph_attn_test(null, null, null, null, null, null, 1, 50, 12, 0, null),
+        'aph_allreduce_f32': lambda: L.aph_allreduce_f32(null, null, ctypes.c_size_t(1), null),
     }
     for name, call in cases.items():
         rc = call()
