@@ -39,8 +39,7 @@ class _Fast(Transform):
     def draw(self, size):
         prm = dict(persp=None, erase=None, angle=0.0)
         if _RU.uniform_().item() < 0.2:              # `torch.rand(1) < p` (fp32 compare; 0.2f > 0.2 and no fp32 lies between)
-            sp, ep = _perspective_params(size, size, 0.33)
-            prm['persp'] = _perspective_coeffs(sp, ep)
+            prm['persp'] = _PendingPersp(*_perspective_params(size, size, 0.33))     # solved in one batch by finish_draws()
         if _RU.uniform_().item() < 0.2:
             prm['erase'] = _erase_params(size, size)
         prm['angle'] = float(ROT_ANGLES_FAST[np.random.randint(0, len(ROT_ANGLES_FAST))])   # == np.random.choice (same stream), transforms.py:75
@@ -58,6 +57,7 @@ transforms_fast = _Fast()
 _EXACT_ZERO_ROT = os.environ.get('APH_EXACT_ZERO_ROTATION') == '1'
 _RI = torch.empty(1, dtype=torch.int64)
 _RU = torch.empty(1)
+_LOG_RATIO = {}
 
 
 def _perspective_params(width, height, distortion_scale):
@@ -73,13 +73,47 @@ def _perspective_params(width, height, distortion_scale):
     return [[0, 0], [width - 1, 0], [width - 1, height - 1], [0, height - 1]], [tl, tr, br, bl]
 
 
+class _PendingPersp:
+    """start / end points of a drawn perspective whose 8 coefficients are still to be solved (the solve consumes no random numbers)"""
+    __slots__ = ('sp', 'ep')
+
+    def __init__(self, sp, ep):
+        self.sp, self.ep = sp, ep
+
+
+def finish_draws(prms):
+    """Solve the perspective systems of a list of per-cut parameter dicts in ONE batched fp64 solve (a seeded `--rng reference` run
+    draws ~40 of them per step; one at a time they cost more host time than the GPU step takes)."""
+    pend = [p for p in prms if isinstance(p.get('persp'), _PendingPersp)]
+    if not pend:
+        return prms
+    e = np.asarray([p['persp'].ep for p in pend], dtype=np.float64)          # [n,4,2]
+    st = np.asarray([p['persp'].sp for p in pend], dtype=np.float64)
+    a = np.zeros((len(pend), 8, 8), dtype=np.float64)
+    a[:, 0::2, 0:2] = e
+    a[:, 0::2, 2] = 1.0
+    a[:, 0::2, 6:8] = -st[:, :, 0:1] * e
+    a[:, 1::2, 3:5] = e
+    a[:, 1::2, 5] = 1.0
+    a[:, 1::2, 6:8] = -st[:, :, 1:2] * e
+    sol = np.linalg.solve(a, st.reshape(len(pend), 8, 1))[..., 0].astype(np.float32)
+    for p, c in zip(pend, sol):
+        p['persp'] = c.tolist()
+    return prms
+
+
 def _perspective_coeffs(startpoints, endpoints):
     """8 coefficients mapping output (endpoint) to input (startpoint) coordinates, least squares in fp64."""
+    e = np.asarray(endpoints, dtype=np.float64)             # p1 rows
+    st = np.asarray(startpoints, dtype=np.float64)          # p2 rows
     a = np.zeros((8, 8), dtype=np.float64)
-    for i, (p1, p2) in enumerate(zip(endpoints, startpoints)):
-        a[2 * i] = [p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]]
-        a[2 * i + 1] = [0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]]
-    b = np.asarray(startpoints, dtype=np.float64).reshape(8)
+    a[0::2, 0:2] = e
+    a[0::2, 2] = 1.0
+    a[0::2, 6:8] = -st[:, 0:1] * e
+    a[1::2, 3:5] = e
+    a[1::2, 5] = 1.0
+    a[1::2, 6:8] = -st[:, 1:2] * e
+    b = st.reshape(8)
     # torchvision solves this square full-rank system with lstsq(gels) in fp64 and casts to fp32; a direct fp64 solve
     # agrees to ~1e-14 before the cast
     return np.linalg.solve(a, b).astype(np.float32).tolist()
@@ -87,10 +121,13 @@ def _perspective_coeffs(startpoints, endpoints):
 
 def _erase_params(img_h, img_w, scale=(0.02, 0.33), ratio=(0.3, 3.3)):
     area = img_h * img_w
-    log_ratio = torch.log(torch.tensor(ratio))
+    lr = _LOG_RATIO.get(ratio)
+    if lr is None:
+        t = torch.log(torch.tensor(ratio))                   # fp32 log as torchvision computes it; the bounds reach uniform_ as doubles
+        lr = _LOG_RATIO[ratio] = (t[0].item(), t[1].item())
     for _ in range(10):
         erase_area = area * _RU.uniform_(scale[0], scale[1]).item()
-        aspect = torch.exp(_RU.uniform_(log_ratio[0], log_ratio[1])).item()
+        aspect = torch.exp(_RU.uniform_(lr[0], lr[1])).item()
         h = int(round(math.sqrt(erase_area * aspect)))
         w = int(round(math.sqrt(erase_area / aspect)))
         if not (h < img_h and w < img_w):
@@ -103,13 +140,14 @@ def _erase_params(img_h, img_w, scale=(0.02, 0.33), ratio=(0.3, 3.3)):
 
 def pack_aug(prms):
     """list of per-cut dicts (persp / erase / angle) -> f32 [S,16] table for aph_sample_fwd (host tensor)."""
-    t = torch.zeros(len(prms), _ffi.APH_AUG_STRIDE, dtype=torch.float32)
+    finish_draws(prms)
+    t = np.zeros((len(prms), _ffi.APH_AUG_STRIDE), dtype=np.float32)
     for s, p in enumerate(prms):
         if p.get('persp') is not None:
-            t[s, 0:8] = torch.tensor(p['persp'], dtype=torch.float32)
+            t[s, 0:8] = p['persp']
             t[s, 8] = 1.0
         if p.get('erase') is not None:
-            t[s, 9:13] = torch.tensor([float(v) for v in p['erase']])
+            t[s, 9:13] = p['erase']
         ang = p.get('angle')
         if ang is not None:
             rot = math.radians(float(ang))
@@ -119,7 +157,7 @@ def pack_aug(prms):
             # quarter of the rotation kernels' work.  APH_EXACT_ZERO_ROTATION=1 restores the resampling.
             has_rot = 1.0 if (float(ang) != 0.0 or _EXACT_ZERO_ROT) else 0.0
             t[s, 13], t[s, 14], t[s, 15] = math.cos(rot), math.sin(rot), has_rot
-    return t
+    return torch.from_numpy(t)
 
 
 # ----------------------------------------------------------------------------- bulk (vectorised) draws

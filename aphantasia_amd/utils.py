@@ -74,6 +74,9 @@ class _Slice(torch.autograd.Function):
         return d.reshape(ctx.shape), None, None, None, None
 
 
+_RU1 = torch.empty(1)
+
+
 def draw_crop_params_multi(count, size, hw_list, align='uniform', macro=0., transform=None):
     """slice_imgs' draws for a LIST of images (utils.py:222-228 once, then utils.py:238-253 per image): the size / offset
     vectors are drawn once and shared by every image; the per-cut macro draw and the transform's draws repeat per image, in
@@ -97,7 +100,7 @@ def draw_crop_params_multi(count, size, hw_list, align='uniform', macro=0., tran
         table = np.empty((count, 3), dtype=np.int32)
         augs = [] if geometric else None
         for c in range(count):
-            if f32(torch.rand(1).item()) < f32(macro):
+            if f32(_RU1.uniform_().item()) < f32(macro):          # == torch.rand(1) on the global generator, without the allocation
                 csize = int(rnd_size[c] * (f32(sz_max) - big_min) + big_min)
             else:
                 csize = int(rnd_size[c] * f32(sz_max - size) + f32(size))
@@ -106,6 +109,9 @@ def draw_crop_params_multi(count, size, hw_list, align='uniform', macro=0., tran
             table[c, 2] = int(rnd_offy[c] * f32(ph - csize))
             if geometric:
                 augs.append(transform.draw(size))
+        if geometric:
+            from .transforms import finish_draws
+            finish_draws(augs)
         out.append((table, augs))
     return out
 
