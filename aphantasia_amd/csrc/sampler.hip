@@ -329,8 +329,11 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
           const int s = v / (nay * nax), al = v - s * (nay * nax), ay = al / nax, ax = al - ay * nax;
           const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
           // alias coordinates of the tile's first/last row and column (a wrapping tile is not culled on that axis)
-          const int Ya = wrap(ty0 + g.py0, g.H) + ay * g.H, Yb = wrap(ty0 + 15 + g.py0, g.H) + ay * g.H;
-          const int Xa = wrap(tx0 + g.px0, g.W) + ax * g.W, Xb = wrap(tx0 + 15 + g.px0, g.W) + ax * g.W;
+          // (the LAST LIVE row / column: a tile taller or wider than the whole image must not wrap its end into the middle of it --
+          // images under 16 pixels on a side lost every cut that misses their first rows)
+          const int ylast = ty0 + 15 < g.H - 1 ? ty0 + 15 : g.H - 1, xlast = tx0 + 15 < g.W - 1 ? tx0 + 15 : g.W - 1;
+          const int Ya = wrap(ty0 + g.py0, g.H) + ay * g.H, Yb = wrap(ylast + g.py0, g.H) + ay * g.H;
+          const int Xa = wrap(tx0 + g.px0, g.W) + ax * g.W, Xb = wrap(xlast + g.px0, g.W) + ax * g.W;
           const bool yhit = Yb < Ya ? true : (Yb >= oy && Ya < oy + cs);
           const bool xhit = Xb < Xa ? true : (Xb >= ox && Xa < ox + cs);
           hit = yhit && xhit;

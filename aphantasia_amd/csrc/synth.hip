@@ -6,7 +6,7 @@
 // Replaces: aphantasia/image.py:164-175 (fft_image.inner), :21-28 (to_valid_rgb.inner),
 //           :114-118 (pixel_image.inner).  All arithmetic fp32, reductions in fp64.
 //
-// FFT: Stockham autosort, mixed radix (2/3/4/5 specialised, any other prime <= 31 generic),
+// FFT: Stockham autosort, mixed radix (2/3/4/5 specialised, any other prime <= 31 generic in registers, larger primes by direct sums),
 // one workgroup per column tile / per row PAIR, whole sequence resident in LDS (ping-pong).
 // The C2R / R2C row transforms process two real rows as one complex sequence
 // (z = a + i b), which halves the work and keeps odd W legal.
@@ -109,6 +109,31 @@ __device__ void fft_pass_generic(const float2* src, float2* dst, int N, int R, i
   }
 }
 
+// any larger prime radix (37, 41, ... up to N itself): the R inputs of a butterfly do not fit registers, so a work item is ONE
+// output: y[qq] = sum_r x[j + r nb] w^(k r tscale + (qq r mod R) nb), the two twiddles folded into one table index.  O(N R) per pass
+// instead of O(N log N): sizes with a big prime factor (1366 = 2 x 683) are transformed correctly, just not fast -- torch.fft takes
+// any size, and a --size the reference accepts must not be refused here.
+template <int SIGN>
+__device__ void fft_pass_large(const float2* src, float2* dst, int N, int R, int Ns, int nseq, const float2* __restrict__ tw) {
+  const int nb = N / R;
+  const int tscale = N / (Ns * R);
+  for (int idx = threadIdx.x; idx < N * nseq; idx += blockDim.x) {
+    const int q = idx / N, o = idx - q * N;
+    const int qq = o / nb, j = o - qq * nb;
+    const int k = j % Ns;
+    const float2* x = src + q * N;
+    float2 acc = x[j];
+    // twiddle index of term r: r (k tscale + qq nb) mod N  (N = R nb, so (qq r mod R) nb == qq r nb mod N): one modular add per term
+    const int step = (int)(((long long)k * tscale + (long long)qq * nb) % N);
+    int t = 0;
+    for (int r = 1; r < R; ++r) {
+      t += step; if (t >= N) t -= N;
+      acc = cadd(acc, cmul(x[j + r * nb], twiddle<SIGN>(tw, t)));
+    }
+    dst[q * N + (j / Ns) * Ns * R + k + qq * Ns] = acc;
+  }
+}
+
 // Full transform of nseq LDS-resident sequences; returns the buffer holding the result.
 template <int SIGN>
 __device__ float2* fft_lds(float2* a, float2* b, const Fft1D& plan, int nseq, const float2* __restrict__ tw) {
@@ -121,7 +146,10 @@ __device__ float2* fft_lds(float2* a, float2* b, const Fft1D& plan, int nseq, co
       case 3: fft_pass<SIGN, 3>(a, b, N, Ns, nseq, tw); break;
       case 4: fft_pass<SIGN, 4>(a, b, N, Ns, nseq, tw); break;
       case 5: fft_pass<SIGN, 5>(a, b, N, Ns, nseq, tw); break;
-      default: fft_pass_generic<SIGN>(a, b, N, R, Ns, nseq, tw); break;
+      default:
+        if (R <= 31) fft_pass_generic<SIGN>(a, b, N, R, Ns, nseq, tw);
+        else fft_pass_large<SIGN>(a, b, N, R, Ns, nseq, tw);
+        break;
     }
     __syncthreads();
     float2* t = a; a = b; b = t;
@@ -513,9 +541,10 @@ static bool factorize(int n, Fft1D* p) {
   auto push = [&](int r) { if (p->npass >= 14) return false; p->radix[p->npass++] = r; return true; };
   while (m % 4 == 0) { if (!push(4)) return false; m /= 4; }
   while (m % 2 == 0) { if (!push(2)) return false; m /= 2; }
-  for (int r = 3; r <= 31; r += 2)
+  for (int r = 3; (long long)r * r <= m || r <= 31; r += 2)
     while (m % r == 0) { if (!push(r)) return false; m /= r; }
-  return m == 1;
+  if (m > 1 && !push(m)) return false;             // the remaining factor is a prime > 31 (fft_pass_large)
+  return true;
 }
 
 static float2* make_twiddles(int n) {
@@ -539,7 +568,7 @@ int aph_synth_plan_create(int C, int H, int W, aph_synth_plan** out) {
   p->C = C; p->H = H; p->W = W; p->Wc = W / 2 + 1;
   if (!factorize(H, &p->ph) || !factorize(W, &p->pw)) {
     delete p;
-    return aph_fail(APH_ERR_UNSUPPORTED, "FFT size %dx%d has a prime factor > 31 (supported: factors 2..31)", W, H);
+    return aph_fail(APH_ERR_UNSUPPORTED, "FFT size %dx%d has more than 14 prime factors", W, H);
   }
   if (W > 8192 || H > 8192) { delete p; return aph_fail(APH_ERR_UNSUPPORTED, "FFT dimension > 8192 not supported (%dx%d)", W, H); }
   int tc = (64 * 1024) / (H * 8);

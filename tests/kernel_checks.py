@@ -518,3 +518,43 @@ def check_attention(lib, dev, S, T, heads, seed=0):
     err = (dqkv.float().cpu() - ref_in.grad).abs().max().item()
     assert err < 8e-3 * ref_in.grad.abs().max().item(), (S, T, heads, err, ref_in.grad.abs().max().item())
     return att, dqkv
+
+
+def check_sampler_fuzz(lib, dev, seed, n, max_hw=(90, 120)):
+    """Random ragged geometries (image sides from just above the cut size, all --align modes, every output layout, with and without the
+    -tf fast chain, 1..8 cuts): forward and adjoint vs the oracle.  Found the cull bug of images under 16 pixels on a side."""
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        size = int(rng.choice([8, 16, 32]))
+        patch = int(rng.choice([4, 8]))
+        H = int(rng.integers(size + 1, max_hw[0])); W = int(rng.integers(size + 1, max_hw[1]))
+        S = int(rng.integers(1, 9)); align = str(rng.choice(['uniform', 'central', 'overscan', 'overmax']))
+        mode = int(rng.choice([_ffi.APH_OUT_NCHW_RAW, _ffi.APH_OUT_NCHW_NORM, _ffi.APH_OUT_PATCH_F16]))
+        aug = bool(rng.integers(0, 2))
+        sd = int(rng.integers(0, 10000))
+        seed_all(sd)
+        case = dict(size=size, patch=patch, H=H, W=W, S=S, align=align, mode=mode, aug=aug, seed=sd)
+        img = torch.rand(1, 3, H, W).requires_grad_(True)
+        table = R.draw_crop_table(S, size, H, W, align, 0.4)
+        prm = [augment_ref.draw_fast_params(size) for _ in range(S)] if aug else None
+        tf = None if mode == _ffi.APH_OUT_NCHW_RAW else R.normalize
+        if aug:
+            ident = lambda x: x
+            cuts = R.slice_imgs(img, table, size, align, transform=tf, per_cut=lambda c, cut: augment_ref.apply_fast(cut, prm[c], tf if tf is not None else ident))
+        else:
+            cuts = R.slice_imgs(img, table, size, align, transform=tf)
+        gout = torch.randn_like(cuts)
+        (cuts * gout).sum().backward()
+        geom = ops.make_geom(H, W, S, size, patch=patch, align=align)
+        tb = torch.from_numpy(table).to(dev)
+        augt = pack_aug(prm).to(dev) if aug else None
+        got = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=augt, out_mode=mode, lib=lib).cpu()
+        want = cuts.detach()
+        if mode == _ffi.APH_OUT_PATCH_F16:
+            want, got = to_patch_major(want, patch).half().float(), got.float()
+        e1 = (got - want).abs().max().item()
+        assert e1 < (4e-3 if mode == _ffi.APH_OUT_PATCH_F16 else 1e-4), (case, e1)
+        gin = to_patch_major(gout, patch) if mode == _ffi.APH_OUT_PATCH_F16 else gout
+        gb = ops.sample_bwd(geom, gin.to(dev).contiguous(), tb, aug=augt, out_mode=mode, gscale=1.0, lib=lib).cpu()
+        e2 = (gb - img.grad[0]).abs().max().item() / max(img.grad.abs().max().item(), 1e-9)
+        assert e2 < 2e-4, (case, e2)

@@ -38,6 +38,8 @@ def test_dwt(emu):
 def test_fft_pair(emu):
     K.check_fft_pair(emu, 'cpu', 24, 40)
     K.check_fft_pair(emu, 'cpu', 21, 27)
+    K.check_fft_pair(emu, 'cpu', 74, 51)      # 2 x 37 (a prime factor > 31: the direct-sum pass), 3 x 17
+    K.check_synth_vs_oracle(emu, 'cpu', 41, 86, 1.1, with_shift=True)      # 41 prime, 2 x 43
 
 
 def test_synth_spatial(emu):
@@ -130,3 +132,13 @@ def test_attention_alone(emu):
     K.check_attention(emu, 'cpu', S=5, T=50, heads=2)       # 10 (cut, head) items on 3 persistent workgroups: 4 / 3 / 3 items each
     K.check_attention(emu, 'cpu', S=1, T=60, heads=1)       # one item, 64-row tiles
     K.check_attention(emu, 'cpu', S=2, T=82, heads=1)       # blocked kernels (T > 64)
+
+
+def test_sampler_small_image_and_random_geometries(emu, monkeypatch):
+    # regression: images under 16 pixels on a side (a 16 x 16 adjoint tile larger than the image) lost cuts in the adjoint's cull
+    for align in ('uniform', 'overscan', 'overmax'):
+        for H in (13, 15):
+            K.check_sampler_adjoint(emu, 'cpu', align, _ffi.APH_OUT_NCHW_RAW, H=H, W=72, S=4, size=8, patch=8)
+            K.check_sampler_adjoint(emu, 'cpu', align, _ffi.APH_OUT_PATCH_F16, H=72, W=H, S=4, size=8, patch=8)
+    monkeypatch.setattr('aphantasia_amd.transforms._EXACT_ZERO_ROT', True)       # (the oracle resamples 0-degree cuts too)
+    K.check_sampler_fuzz(emu, 'cpu', seed=11, n=14)

@@ -28,6 +28,8 @@ def test_fft_pair():
     K.check_fft_pair(None, DEV, 24, 40)
     K.check_fft_pair(None, DEV, 45, 63)
     K.check_fft_pair(None, DEV, 720, 1280)
+    K.check_fft_pair(None, DEV, 768, 1366)    # 1366 = 2 x 683: a large prime factor (direct-sum pass), as torch.fft accepts any size
+    K.check_synth_vs_oracle(None, DEV, 37 * 6, 101 * 4, 1.0)
 
 
 def test_depthwarp_vs_reference_golden_and_oracle(golden):
@@ -101,6 +103,15 @@ def test_attention_backward_is_deterministic():
     a1, d1 = K.check_attention(None, DEV, S=190, T=50, heads=12)
     a2, d2 = K.check_attention(None, DEV, S=190, T=50, heads=12)
     assert torch.equal(a1, a2) and torch.equal(d1, d2)
+
+
+def test_sampler_random_geometries(monkeypatch):
+    """ragged images / every align mode / every layout / with and without -tf fast, forward + adjoint vs the oracle"""
+    monkeypatch.setattr('aphantasia_amd.transforms._EXACT_ZERO_ROT', True)       # (the oracle resamples 0-degree cuts too)
+    K.check_sampler_fuzz(None, DEV, seed=5, n=60)
+    K.check_sampler_fuzz(None, DEV, seed=6, n=12, max_hw=(400, 700))
+    for H in (13, 15):
+        K.check_sampler_adjoint(None, DEV, 'overscan', 0, H=H, W=72, S=4, size=8, patch=8)
 
 
 def test_gemm_mfma_layout():
