@@ -182,6 +182,15 @@ __device__ __forceinline__ float dot2_f16(half2 a, half2 b, float c) {
 #endif
 }
 
+// 1 / x by v_rcp_f32 (1 ulp)
+__device__ __forceinline__ float fast_rcp(float x) {
+#ifdef APH_EMU
+  return 1.0f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // Zero-fill as a KERNEL (16 bytes per lane, grid-stride).  The step's launch sequence is captured into a hipGraph; with

@@ -11,6 +11,7 @@
 #include "aph_device.h"
 #include "aph_host.h"
 #include "vit_gemm.h"
+#include "vit_gemm_ws.h"
 #include "vit_ops.h"
 #include "vit_attn.h"
 
@@ -407,6 +408,33 @@ int aph_gemm_set_mfma32(int on) {
   return prev;
 }
 
+// tile-count threshold from which launch_gemm picks the wave-specialised persistent kernel (0 = never).  Returns the previous value.
+int aph_gemm_set_ws_min_tiles(int tiles) {
+  const int prev = gemm_ws_min_tiles();
+  gemm_ws_min_tiles() = tiles < 0 ? 0 : tiles;
+  return prev;
+}
+
+// Measurement hook: the wave-specialised GEMM with one of the ViT's real epilogues and per-tile shader-clock stamps.
+// epi_kind 0 = f16 + bias (QKV), 1 = QuickGELU (two f16 outputs: d_out, d_out2), 2 = f32 residual (d_out f32 in/out pitch N, d_bias),
+// 3 = no store.  d_trace: gridDim x 16 tiles x 4 uint64 {first k-tile done, main loop done, epilogue issued, -} of consumer wave 0, or null.
+int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, void* d_out2, const float* d_bias, int epi_kind,
+                      unsigned long long* d_trace, void* stream_) {
+  APH_TRY
+  if (!d_A || !d_Bt || !d_out || M < 1 || N % 128 || K % GEMM_BK || N > 4096 || !gemm8_addressable(M, K, N, K))
+    return aph_fail(APH_ERR_ARG, "aph_gemm_ws_probe: bad shape");
+  const half_t* A = (const half_t*)d_A;
+  const half_t* B = (const half_t*)d_Bt;
+  hipStream_t st = (hipStream_t)stream_;
+  if (epi_kind == 0) launch_gemm_ws(A, K, B, K, M, N, K, EpiF16{(half_t*)d_out, N, d_bias}, st, d_trace);
+  else if (epi_kind == 1 && d_out2 && d_bias) launch_gemm_ws(A, K, B, K, M, N, K, EpiGelu{(half_t*)d_out2, (half_t*)d_out, N, d_bias}, st, d_trace);
+  else if (epi_kind == 2 && d_bias) launch_gemm_ws(A, K, B, K, M, N, K, EpiResidual{(float*)d_out, (const float*)d_out, N, d_bias}, st, d_trace);
+  else if (epi_kind == 3) launch_gemm_ws(A, K, B, K, M, N, K, EpiNoStore{(float*)d_out, N}, st, d_trace);
+  else return aph_fail(APH_ERR_ARG, "aph_gemm_ws_probe: bad epilogue kind / missing buffer");
+  return aph_check_launch("aph_gemm_ws_probe");
+  APH_CATCH
+}
+
 // the attention kernels alone (unit tests, micro-benchmarks): mode 0 = forward (qkv -> att, lse), 1 = backward
 // ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16, att / datt [S*T, heads*64] f16, lse [S*heads*T] f32,
 // d_delta: S*heads*T floats of scratch, needed by the backward when T > 64.
@@ -434,20 +462,31 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 }
 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
-// (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 8 / 9 = 64x64 split-K x2 / x4,
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 5 = 256x128 wave-specialised persistent, 8 / 9 = 64x64 split-K x2 / x4,
 // 10 = 128x128 4-stage, 11 = 128x128 4 waves 2-stage (two workgroups per CU), 12 = 256x128 on 4 waves, 22 / 24 = 128x128 split-K x2 / x4) -- unit tests and tuning sweeps
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
+  const bool nostore = (tile_cfg & 0x100) != 0;
+  tile_cfg &= 0xff;
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || (tile_cfg >= 8 && tile_cfg <= 12) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))))
+      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
   const EpiF32 epi{d_C, N, 1.0f};
   hipStream_t st = (hipStream_t)stream_;
+  if (nostore) {          // measurement only: the same main loops with the output stores compiled out of the taken path
+    const EpiNoStore en{d_C, N};
+    if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, en, st);
+    else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, en, st);
+    else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, en, st, nullptr);
+    else return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: the no-store variant exists for tile_cfg 2, 4 and 5");
+    return aph_check_launch("aph_gemm_f16_ld");
+  }
   if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
+  else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, epi, st, nullptr);
   else if (tile_cfg == 8 || tile_cfg == 9 || tile_cfg == 22 || tile_cfg == 24) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
     static SplitKSpace sp;
     const int splits = (tile_cfg == 8 || tile_cfg == 22) ? 2 : 4;

@@ -585,6 +585,13 @@ struct EpiF32 {          // out = acc * scale  (fp32)
   }
 };
 
+struct EpiNoStore {       // measurement hook: keeps the accumulators live, stores only on a value that never occurs
+  float* out; int ldo;
+  __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const {
+    if (a[0] == 1.2345678e33f) { st4(out + (size_t)m * ldo + n, a); st4(out + (size_t)m * ldo + n + 4, b); }
+  }
+};
+
 struct EpiF16Scale {     // out = acc * scale (f16)
   half_t* out; int ldo; float scale;
   __device__ __forceinline__ void apply8(int m, int n, f32x4 a, f32x4 b) const { store_h8(out + (size_t)m * ldo + n, a * scale, b * scale); }
@@ -604,9 +611,9 @@ struct EpiResidual {     // out = res + acc + bias   (fp32 residual stream)
 __device__ __forceinline__ void quick_gelu4(const f32x4& u, f32x4& g, f32x4& dg) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float s = 1.0f / (1.0f + __expf(-1.702f * u[i]));
+    const float s = fast_rcp(1.0f + __expf(-1.702f * u[i]));      // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the outputs are f16
     g[i] = u[i] * s;
-    dg[i] = s * (1.0f + 1.702f * u[i] * (1.0f - s));
+    dg[i] = s + 1.702f * (g[i] - g[i] * s);                        // = s (1 + 1.702 u (1 - s))
   }
 }
 struct EpiGelu {
@@ -642,6 +649,9 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
   }
 };
 
+#ifndef APH_GEMM_WS_MIN_TILES_DEFAULT
+#define APH_GEMM_WS_MIN_TILES_DEFAULT 160
+#endif
 // MFMA shape of the main loops: 1 = v_mfma_f32_32x32x16_f16, 0 = v_mfma_f32_16x16x32_f16.  Default below; the environment
 // variable APH_GEMM_MFMA32 (read once) or aph_gemm_set_mfma32() override it for A/B measurements.
 #ifndef APH_GEMM_MFMA32_DEFAULT
@@ -749,9 +759,22 @@ inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, in
 //   128x128, 8 waves, 4-stage ring   >= 160 such tiles (half-batch shards with N = 768, wide outputs of small shards)
 //   64x64 (2 workgroups per CU)      everything smaller; split-K when only a handful of tiles exist
 template <class Epi>
+inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
+                           unsigned long long* trace = nullptr);   // vit_gemm_ws.h
+// the wave-specialised persistent kernel takes every shape with at least this many 256x128 tiles (APH_GEMM_WS_MIN_TILES; 0 = never)
+inline int& gemm_ws_min_tiles() {
+  static int v = [] { const char* e = getenv("APH_GEMM_WS_MIN_TILES"); return e ? atoi(e) : APH_GEMM_WS_MIN_TILES_DEFAULT; }();
+  return v;
+}
+
+template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                         const SplitKSpace* sp = nullptr) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
+  if (gemm_ws_min_tiles() > 0 && big_tiles >= gemm_ws_min_tiles() && N <= 4096 /* GemmWS::BIAS_MAX */ && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32()) {
+    launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
+    return;
+  }
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
   static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)

@@ -197,7 +197,7 @@ class Engine:
                         t.zero_()
                 self._state['step'][0] = 0
 
-    def set_prev_enc(self, enc_rows=None):
+    def set_prev_enc(self, enc_rows=None, active=True):
         """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
         target of the next step with coefficient +expand (clip_fft.py:276-280: `loss += a.expand * sim_func(out_enc, prev_enc)`)."""
         if not self.expand > 0:
@@ -208,9 +208,10 @@ class Engine:
         D = self.targets.shape[1]
         row0 = self.n_broadcast + (len(self.coef) - 1 - self.n_broadcast) * self.S + self.lo
         self.targets[row0:row0 + self.S_loc].copy_(enc_rows[:self.S_loc].reshape(-1, D))
-        if self.coef[-1] != self.expand:
-            self.coef[-1] = self.expand
-            self.dcoef[-1:].fill_(self.expand)
+        want = self.expand if active else 0.0      # (`active=False`: keep the encodings, leave the term out -- illustrip's `if ii > 0`)
+        if self.coef[-1] != want:
+            self.coef[-1] = want
+            self.dcoef[-1:].fill_(want)
             self.hcoef = _ffi.floats(self.coef)
 
     # ------------------------------------------------------------------

@@ -73,6 +73,13 @@ class FrameLoop:
             if noise > 0 and self.gen == 'FFT':                                                             # illustrip.py:429
                 sh = (noise * (torch.rand(self.h, self.w // 2 + 1) - 0.5)).to(e.dev).contiguous()
             e.step(lr=lr, shift=sh)
+            if self.eng.expand > 0:
+                # illustrip.py:459-463: `prev_enc = out_enc.detach()` after EVERY step; the term `a.expand * sim_func(prev_enc, out_enc)`
+                # is part of the loss from the line's second frame on (`if ii > 0`), whichever CLIP model produced prev_enc
+                nxt = ii if ss + 1 < self.opt_step else ii + 1          # frame index of the step that will read it
+                for other in (self.eng, self.eng2):
+                    if other is not None:
+                        other.set_prev_enc(e.enc, active=nxt > 0)
         self.frames += 1
         if contrast is not None:
             return self.eng.synthesize(contrast)                                                             # illustrip.py:478

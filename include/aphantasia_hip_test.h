@@ -24,10 +24,13 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 /* same with explicit row pitches (elements, multiples of 8) and an explicit tile configuration:
  *    0  automatic (the shape heuristic of launch_gemm)
  *    1  64x64, 4 waves            2  256x128, 8 waves, 3-stage ring       4  256x256 phased (needs N % 256 == 0)
+ *    5  256x128 wave-specialised persistent (2 DMA producer waves + 8 MFMA consumer waves, register epilogue: vit_gemm_ws.h)
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
  *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
  *   22 / 24  128x128 split-K x2 / x4
+ * | 0x100 (with 2, 4 or 5 only): measurement variant whose epilogue keeps the accumulators live but never stores (upper bound of
+ *   what overlapping the store phase could gain: tools/exp/gemm_nostore.py).
  * any other value is rejected (APH_ERR_ARG). */
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
                     void* stream);
@@ -36,6 +39,16 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
  * faster on MI355X with real operands -- the chip is power-limited there and the 32x32x16 form sustains less),
  * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
 int aph_gemm_set_mfma32(int on);
+/* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
+ * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
+ * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
+int aph_gemm_set_ws_min_tiles(int tiles);
+/* The wave-specialised GEMM (tile_cfg 5) with one of the ViT's real epilogues and optional per-tile shader-clock stamps
+ * (tools/exp/gemm_ws_trace.py).  A [M,K], Bt [N,K] f16 dense; epi_kind 0: d_out f16 [M,N] = acc + bias; 1: QuickGELU, d_out = g,
+ * d_out2 = dg/du (both f16); 2: d_out f32 [M,N] += acc + bias (residual in place); 3: nothing stored.
+ * d_trace: (workgroups x 16 x 4) uint64 or NULL. */
+int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, void* d_out2, const float* d_bias, int epi_kind,
+                      unsigned long long* d_trace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,21 @@ def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(70, 128, 192)], tile_cfg=8)
     K.check_gemm(emu, 'cpu', [(200, 256, 320)], tile_cfg=10)   # 128x128, 8 waves, 4-stage ring
     K.check_gemm(emu, 'cpu', [(70, 128, 64)], tile_cfg=2)     # single k-tile, single partial tile
+    # wave-specialised persistent kernel (vit_gemm_ws.h): producer / consumer waves, permuted Bt rows, register epilogue;
+    # single unit, ragged single tile, 9 / 10 tiles on 3 workgroups with odd and even k-tile counts
+    K.check_gemm(emu, 'cpu', [(70, 128, 64), (300, 256, 192), (700, 768, 192), (1100, 512, 128)], tile_cfg=5, variants=(0,))
+
+
+def test_vit_through_the_wave_specialised_gemm(emu):
+    """every ViT epilogue (f16 + bias, QuickGELU, its backward, fp32 residual with the accumulators started from it, patch embedding,
+    f16 / f32 input gradient) on the wave-specialised kernel, forced at sizes the interpreter can run"""
+    prev = emu.cdll.aph_gemm_set_ws_min_tiles(1)
+    try:
+        K.check_vit(emu, 'cpu')
+        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)      # T = 17
+        K.check_vit(emu, 'cpu', cfg, S=20)        # M = 340: two row tiles, the second ragged
+    finally:
+        emu.cdll.aph_gemm_set_ws_min_tiles(prev)
 
 
 def test_vit(emu):

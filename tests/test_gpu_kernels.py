@@ -125,6 +125,37 @@ def test_gemm_every_tile_config():
     K.check_gemm(None, DEV, [(9500, 3072, 768), (18715, 3072, 768)], tile_cfg=4, variants=(0,))   # persistent loop: 456 / 888 tiles on 256 CUs
 
 
+def test_gemm_wave_specialised_vs_matmul_and_reproducible():
+    """tile_cfg 5 (vit_gemm_ws.h): every ViT-B shape at full batch and ragged / single-tile cases against fp32 matmul, and the SAME BITS
+    on every launch -- the interpreter cannot see a vmcnt under-wait or a stage refilled too early; a race shows up here as a changing tile"""
+    import torch
+    from aphantasia_amd import ops
+    K.check_gemm(None, DEV, [(9500, 2304, 768), (9500, 768, 768), (9500, 3072, 768), (9500, 768, 3072), (9500, 768, 2304), (70, 128, 64),
+                             (333, 256, 64), (18715, 3072, 768)], tile_cfg=5, variants=(0,))
+    g = torch.Generator().manual_seed(7)
+    for (M, N, Kd) in ((9500, 2304, 768), (9500, 768, 3072), (4750, 3072, 768)):
+        A = torch.randn(M, Kd, generator=g).half().to(DEV); Bt = torch.randn(N, Kd, generator=g).half().to(DEV)
+        ref = ops.gemm_f16(A, Bt, tile_cfg=5).clone()
+        busy = torch.randn(4096, 4096, device=DEV)
+        for i in range(12):
+            if i % 3 == 0:
+                busy = busy * 1.0001          # uneven load next to the launches
+            assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=5), ref), (M, N, Kd, i)
+
+
+def test_vit_forced_through_the_wave_specialised_gemm():
+    """all of the ViT's epilogues on the wave-specialised kernel at small sizes (the default heuristic only takes shapes with >= 160 tiles)"""
+    from aphantasia_amd import _ffi
+    L = _ffi.lib()
+    prev = L.cdll.aph_gemm_set_ws_min_tiles(1)
+    try:
+        K.check_vit(None, DEV)
+        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
+        K.check_vit(None, DEV, cfg, S=40)
+    finally:
+        L.cdll.aph_gemm_set_ws_min_tiles(prev)
+
+
 def test_gemm_splitk_matches_and_is_deterministic():
     """split-K (tile_cfg 8 / 9): ordered last-block reduction -> same bits on every run, fp32-rounding close to the unsplit kernel"""
     import torch
