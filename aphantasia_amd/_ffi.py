@@ -66,6 +66,7 @@ _PROTOTYPES = {
     'aph_vit_profile_read': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_set_mfma32': (c_int, [c_int]),
     'aph_gemm_set_ws_min_tiles': (c_int, [c_int]),
+    'aph_mfma_rate': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_ws_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_gemm_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_gemm_f16_ld': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -75,6 +76,7 @@ _PROTOTYPES = {
     'aph_comm_unique_id': (c_int, [c_void_p]),
     'aph_comm_init': (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),
     'aph_allreduce_f32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aph_comm_ranks': (c_int, [c_void_p, POINTER(c_int)]),
     'aph_comm_destroy': (c_int, [c_void_p]),
     'aph_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'aph_adam_step_guarded': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),

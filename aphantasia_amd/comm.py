@@ -30,6 +30,12 @@ class Comm:
         self.lib.call('aph_allreduce_f32', self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), st)
         return t
 
+    def ranks_seen(self):
+        """ncclCommCount of the live communicator (bench.py's `rccl_ranks_seen`)"""
+        n = ctypes.c_int(0)
+        self.lib.call('aph_comm_ranks', self.handle, ctypes.byref(n))
+        return n.value
+
     def close(self):
         if getattr(self, 'handle', None):
             self.lib.cdll.aph_comm_destroy(self.handle)
@@ -53,7 +59,9 @@ def _file_exchange(rank, world, uid, key, timeout=300.0):
     """rank 0 publishes the id in a rendezvous file, the others wait for it (all ranks share one node's /tmp).  `key` must be
     unique to this launch (clip_fft.py --ranks passes parent pid + a random port): no freshness heuristics, a slow importer
     simply finds the file already there."""
-    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'aph_rccl_uid_%s' % key)
+    # APH_RDV_DIR: a private (0700) directory created by the spawning parent and removed after the ranks exit (clip_fft.py / illustrip.py /
+    # bench.py); without one (torchrun, where no common parent of ours exists) the launch-keyed name in TMPDIR
+    path = os.path.join(os.environ.get('APH_RDV_DIR') or os.environ.get('TMPDIR', '/tmp'), 'aph_rccl_uid_%s' % key)
     if rank == 0:
         tmp = path + '.%d' % os.getpid()
         with open(tmp, 'wb') as f:
@@ -80,6 +88,21 @@ def _gloo_exchange(rank, world, uid):
         return bytes(t.tolist())
     finally:
         dist.destroy_process_group()
+
+
+def spawn_ranks(fn, args, nranks):
+    """Run `fn(local_rank, *args)` in `nranks` processes of this node (torch.multiprocessing.spawn) with a private 0700 rendezvous
+    directory for the RCCL unique id, exported to the children as APH_RDV_DIR and removed when they have exited."""
+    import shutil
+    import tempfile
+    import torch.multiprocessing as mp
+    rdv = tempfile.mkdtemp(prefix='aph_rdv_')          # mode 0700: nobody else can plant or read the id
+    os.environ['APH_RDV_DIR'] = rdv
+    try:
+        mp.spawn(fn, args=args, nprocs=nranks, join=True)
+    finally:
+        os.environ.pop('APH_RDV_DIR', None)
+        shutil.rmtree(rdv, ignore_errors=True)
 
 
 def create(rank, world, device=None, lib=None, key=None):

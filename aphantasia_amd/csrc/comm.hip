@@ -31,6 +31,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // optional
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -48,6 +49,7 @@ Rccl& rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) r.err = "librccl.so lacks the NCCL 2.x entry points";
   });
@@ -100,6 +102,16 @@ int aph_allreduce_f32(aph_comm* c, float* d_buf, size_t n, void* stream_) {
   APH_CATCH
 }
 
+// number of ranks the COMMUNICATOR itself reports (ncclCommCount): what bench.py prints as `rccl_ranks_seen`
+int aph_comm_ranks(aph_comm* c, int* nranks) {
+  APH_TRY
+  if (!c || !c->comm || !nranks) return aph_fail(APH_ERR_ARG, "aph_comm_ranks: null argument");
+  if (!rccl().CommCount) return aph_fail(APH_ERR_UNSUPPORTED, "aph_comm_ranks: this librccl.so has no ncclCommCount");
+  if (ncclResult_t e = rccl().CommCount(c->comm, nranks)) return rccl_fail("aph_comm_ranks", e);
+  return APH_OK;
+  APH_CATCH
+}
+
 int aph_comm_destroy(aph_comm* c) {
   if (!c) return APH_OK;
   if (c->comm) (void)rccl().CommDestroy(c->comm);
@@ -116,6 +128,7 @@ extern "C" {
 int aph_comm_unique_id(void*) { return aph_fail(APH_ERR_UNSUPPORTED, "aph_comm_unique_id: not available in the host interpreter"); }
 int aph_comm_init(int, int, const void*, aph_comm**) { return aph_fail(APH_ERR_UNSUPPORTED, "aph_comm_init: not available in the host interpreter"); }
 int aph_allreduce_f32(aph_comm*, float*, size_t, void*) { return aph_fail(APH_ERR_UNSUPPORTED, "aph_allreduce_f32: not available in the host interpreter"); }
+int aph_comm_ranks(aph_comm*, int*) { return aph_fail(APH_ERR_UNSUPPORTED, "aph_comm_ranks: not available in the host interpreter"); }
 int aph_comm_destroy(aph_comm*) { return APH_OK; }
 }
 #endif

@@ -415,6 +415,43 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
   return prev;
 }
 
+// Measurement hook (bench.py roofline.peak_measured): a pure v_mfma_f32_16x16x32_f16 loop, 128 accumulator registers per wave, 8 waves
+// per workgroup, no memory traffic inside the loop; operands from d_src (>= 8192 x 16 bytes: zeros run faster than random data -- the part
+// is power limited).  FLOPs of one launch = blocks * 8 waves * iters * 32 MFMAs * 16384.
+namespace {
+__global__ __launch_bounds__(512) void mfma_rate_kernel(const half8* __restrict__ src, float* out, int iters) {
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8 a[8], b[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = src[(threadIdx.x * 16 + i) & 8191];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = src[(threadIdx.x * 16 + 8 + i) & 8191];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32_f16(b[j], a[i], acc[i][j]);
+  }
+  f32x4 s = acc[0][0];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j];
+  if (s[0] == 12345.678f) out[threadIdx.x] = s[1] + s[2] + s[3];
+}
+}  // namespace
+int aph_mfma_rate(int blocks, int iters, const void* d_src, float* d_out, void* stream_) {
+  APH_TRY
+  if (blocks < 1 || iters < 1 || !d_src || !d_out) return aph_fail(APH_ERR_ARG, "aph_mfma_rate: bad argument");
+  APH_LAUNCH(mfma_rate_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream_, (const half8*)d_src, d_out, iters);
+  return aph_check_launch("aph_mfma_rate");
+  APH_CATCH
+}
+
 // Measurement hook: the wave-specialised GEMM with one of the ViT's real epilogues and per-tile shader-clock stamps.
 // epi_kind 0 = f16 + bias (QKV), 1 = QuickGELU (two f16 outputs: d_out, d_out2), 2 = f32 residual (d_out f32 in/out pitch N, d_bias),
 // 3 = no store.  d_trace: gridDim x 16 tiles x 4 uint64 {first k-tile done, main loop done, epilogue issued, -} of consumer wave 0, or null.

@@ -188,11 +188,11 @@ def main(argv=None):
     # WORLD_SIZE / LOCAL_RANK in the environment) or spawned from here with --ranks N.
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if a.ranks > 1 and 'RANK' not in os.environ:
-        import torch.multiprocessing as mp
+        from aphantasia_amd.comm import spawn_ranks
         if a.seed is None:
             argv = list(sys.argv[1:] if argv is None else argv) + ['--seed', str(int.from_bytes(os.urandom(3), 'little'))]    # every rank must draw the same crop tables
         port = 20000 + int.from_bytes(os.urandom(2), 'little') % 20000
-        mp.spawn(_spawn_rank, args=(list(sys.argv[1:] if argv is None else argv), a.ranks, port, 'r%d' % os.getpid()), nprocs=a.ranks, join=True)
+        spawn_ranks(_spawn_rank, (list(sys.argv[1:] if argv is None else argv), a.ranks, port, 'r%d' % os.getpid()), a.ranks)
         return
     comm = None
     if world > 1:

@@ -115,12 +115,12 @@ def main(argv=None):
     # cuts; one RCCL all-reduce of the parameter gradient per step.  The per-frame warp / re-parameterisation is replicated.
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if a.ranks > 1 and 'RANK' not in os.environ:
-        import torch.multiprocessing as mp
+        from aphantasia_amd.comm import spawn_ranks
         args = list(sys.argv[1:] if argv is None else argv)
         if a.seed is None:
             args += ['--seed', str(int.from_bytes(os.urandom(3), 'little'))]
         port = 20000 + int.from_bytes(os.urandom(2), 'little') % 20000
-        mp.spawn(_spawn_rank, args=(args, a.ranks, port, 'i%d' % os.getpid()), nprocs=a.ranks, join=True)
+        spawn_ranks(_spawn_rank, (args, a.ranks, port, 'i%d' % os.getpid()), a.ranks)
         return
     comm = None
     if world > 1:

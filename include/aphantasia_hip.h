@@ -215,6 +215,8 @@ typedef struct aph_comm aph_comm;
 int aph_comm_unique_id(void* h_uid128);
 int aph_comm_init(int rank, int nranks, const void* h_uid128, aph_comm** out);
 int aph_allreduce_f32(aph_comm* comm, float* d_buf, size_t n, void* stream);
+/* the number of ranks the communicator itself reports (ncclCommCount) */
+int aph_comm_ranks(aph_comm* comm, int* nranks);
 int aph_comm_destroy(aph_comm* comm);
 
 #ifdef __cplusplus

@@ -43,6 +43,10 @@ int aph_gemm_set_mfma32(int on);
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
 int aph_gemm_set_ws_min_tiles(int tiles);
+/* Pure-MFMA rate probe (bench.py `roofline.peak_measured`): `blocks` workgroups of 8 waves run `iters` x 32 v_mfma_f32_16x16x32_f16 on
+ * operands read once from d_src (>= 128 KiB of f16; random data sustains less than zeros: the part is power limited), nothing stored unless a
+ * never-true condition holds (d_out: 512 floats).  FLOPs per launch = blocks * 8 * iters * 32 * 16384. */
+int aph_mfma_rate(int blocks, int iters, const void* d_src, float* d_out, void* stream);
 /* The wave-specialised GEMM (tile_cfg 5) with one of the ViT's real epilogues and optional per-tile shader-clock stamps
  * (tools/exp/gemm_ws_trace.py).  A [M,K], Bt [N,K] f16 dense; epi_kind 0: d_out f16 [M,N] = acc + bias; 1: QuickGELU, d_out = g,
  * d_out2 = dg/du (both f16); 2: d_out f32 [M,N] += acc + bias (residual in place); 3: nothing stored.

@@ -1,6 +1,8 @@
 """Kernel checks shared by the CPU (tests/emu interpreter) and GPU (libaphantasia_hip.so) test files.
 Each check drives the C ABI through aphantasia_amd.ops on tensors living on `dev` and compares with the
 oracle (oracle/) or the reference-generated goldens.  lib=None selects the product library."""
+import os
+
 import numpy as np
 import torch
 
@@ -170,6 +172,55 @@ def check_sampler_augment(lib, dev, H=40, W=48, S=6, size=16, patch=8):
     assert torch.equal(pm.cpu(), to_patch_major(out.cpu(), patch).half())
     got = ops.sample_bwd(geom, gout.to(dev).contiguous(), tb, aug=aug, lib=lib)
     assert (got.cpu() - img.grad[0]).abs().max().item() < 3e-4 * img.grad.abs().max().item()
+
+
+TV_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_fast_224.npz')
+
+
+def tv_fixture_or_skip():
+    """the torchvision fixture (oracle/make_tv_fixture.py: needs torchvision, which neither the build image nor the GPU boxes have)"""
+    import pytest
+    if not os.path.isfile(TV_FIXTURE):
+        pytest.skip('PARITY UNPINNED for transforms_fast / frame_transform: tests/golden/tf_fast_224.npz does not exist -- run '
+                    '`python oracle/make_tv_fixture.py` on a machine that has torchvision and /root/reference, commit the file, and this '
+                    'test pins SURVEY rows a-8 / f-1 against torchvision itself')
+    return np.load(TV_FIXTURE)
+
+
+def check_oracle_vs_tv_fixture(fx):
+    """oracle/augment_ref.py (the restated torchvision maths) against outputs of torchvision itself: the seeded transforms_fast
+    stream (op arithmetic + draw order), explicit perspectives, rotations and full affines"""
+    from oracle import make_tv_fixture as F
+    cuts, frame = F.inputs()
+    seed_all(F.STREAM_SEED)
+    got = torch.cat([augment_ref.apply_fast(cuts[c:c + 1], augment_ref.draw_fast_params(F.SIZE), R.normalize) for c in range(F.STREAM_CUTS)], 0)
+    assert (got - torch.from_numpy(fx['stream_out'])).abs().max().item() < 2e-5
+    for i, (sp, ep) in enumerate(F.PERSP_CASES):
+        got = augment_ref.perspective(cuts[i:i + 1], augment_ref.perspective_coeffs(sp, ep))
+        assert (got - torch.from_numpy(fx['persp_out'][i:i + 1])).abs().max().item() < 2e-5, i
+    for i, (a, t, sc, sh) in enumerate(F.AFFINE_CASES):
+        c = i % F.STREAM_CUTS
+        assert (augment_ref.rotate(cuts[c:c + 1], a) - torch.from_numpy(fx['rotate_out'][i:i + 1])).abs().max().item() < 2e-5, i
+        assert (augment_ref.affine(frame, a, t, sc, sh) - torch.from_numpy(fx['affine_out'][i:i + 1])).abs().max().item() < 2e-5, i
+
+
+def check_kernels_vs_tv_fixture(lib, dev, fx):
+    """the HIP sampler's augment stages and aph_frame_affine against torchvision's outputs: every cut is fed as a 224 x 224 image with
+    an identity crop (bicubic taps at integer positions = exact copy), so what is compared is perspective / erase / rotate alone"""
+    from oracle import make_tv_fixture as F
+    from aphantasia_amd import transforms as T
+    cuts, frame = F.inputs()
+    size = F.SIZE
+    geom = ops.make_geom(size, size, 1, size, patch=32)
+    table = torch.tensor([[size, 0, 0]], dtype=torch.int32, device=dev)
+    seed_all(F.STREAM_SEED)
+    for c in range(F.STREAM_CUTS):
+        prm = augment_ref.draw_fast_params(size)
+        out = ops.sample_fwd(geom, cuts[c].to(dev).contiguous(), table, aug=pack_aug([prm]).to(dev), lib=lib).cpu()
+        assert (out - torch.from_numpy(fx['stream_out'][c:c + 1])).abs().max().item() < 2e-4, (c, prm)
+    for i, (a, t, sc, sh) in enumerate(F.AFFINE_CASES):
+        got = T.frame_transform(frame.to(dev), F.FRAME_HW, a, t, sc, sh, lib=lib).cpu()
+        assert (got - torch.from_numpy(fx['affine_out'][i:i + 1])).abs().max().item() < 2e-4, i
 
 
 def check_augment_invariants(lib, dev, size=32, patch=16):

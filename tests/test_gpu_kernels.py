@@ -114,6 +114,11 @@ def test_sampler_random_geometries(monkeypatch):
         K.check_sampler_adjoint(None, DEV, 'overscan', 0, H=H, W=72, S=4, size=8, patch=8)
 
 
+def test_augment_vs_torchvision_fixture():
+    """the sampler's perspective / erase / rotate stages and aph_frame_affine against torchvision's outputs (skips while the fixture is absent)"""
+    K.check_kernels_vs_tv_fixture(None, DEV, K.tv_fixture_or_skip())
+
+
 def test_gemm_mfma_layout():
     K.check_gemm(None, DEV, [(100, 128, 64), (130, 256, 192), (9500, 768, 768), (1000, 3072, 768), (777, 768, 3072)])
 

@@ -170,6 +170,13 @@ def test_augment_oracle_invariants():
     assert abs(float(r[0, 0, n // 2, n // 2]) - 1.0) < 1e-6
 
 
+def test_torchvision_fixture():
+    """a-8 / f-1: the restated torchvision maths against torchvision's own outputs (tests/golden/tf_fast_224.npz, when someone with
+    torchvision has generated it: oracle/make_tv_fixture.py); skipped with the reason otherwise"""
+    import kernel_checks as K
+    K.check_oracle_vs_tv_fixture(K.tv_fixture_or_skip())
+
+
 def test_augment_draw_semantics():
     """RandomErasing.get_params (scale (0.02, 0.33), log-uniform ratio (0.3, 3.3), value 0) and RandomPerspective.get_params
     (distortion 0.33) bounds; the product's host draws consume the same stream as the oracle's restatement"""
