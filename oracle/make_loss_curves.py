@@ -7,6 +7,7 @@ compare the HIP path's own free-running curve with them WITHOUT spending GPU-box
 
 Configurations (seeded synthetic ViT-B/32 weights, `-tf none`, sim 'mix', Adam(lr .05, b1 0), 1280x720):
     c2_s200      200 cuts, 50 steps          (BASELINE configs[1] at its real sample count)
+    c2_s200_200  200 cuts, 200 steps         (BASELINE configs[1] verbatim)
     c2_s32       32 cuts, 200 steps          (BASELINE configs[1]'s step count)
     c2_s32_stress  32 cuts, 60 steps, `weights.stress_visual_weights` (LN gains 0.2-10, massive channels, peaky attention)
 Both sides draw the crop tables with `R.draw_crop_table` after `seed_all(9)`; the parameters start from
@@ -31,6 +32,7 @@ from oracle import reference_path as R                                          
 
 CONFIGS = {
     'c2_s200': dict(h=720, w=1280, S=200, steps=50, weights='synthetic'),
+    'c2_s200_200': dict(h=720, w=1280, S=200, steps=200, weights='synthetic'),     # BASELINE configs[1] verbatim: samples=200, steps=200 (~45 min of CPU)
     'c2_s32': dict(h=720, w=1280, S=32, steps=200, weights='synthetic'),
     'c2_s32_stress': dict(h=720, w=1280, S=32, steps=60, weights='stress'),
 }
@@ -83,5 +85,5 @@ def run(name, full_dir=None):
 if __name__ == '__main__':
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     full = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--full-dir=')), None)
-    for n in (args or list(CONFIGS)):
+    for n in (args or [k for k in CONFIGS if k != 'c2_s200_200']):
         run(n, full)
