@@ -26,7 +26,7 @@
 
 namespace aph {
 
-template <int BM_, int NPROD_, int NSTAGE_, int WG_PER_CU_, int BIAS_MAX_>
+template <int BM_, int NPROD_, int NSTAGE_, int WG_PER_CU_, int BIAS_MAX_, int FORCE_WAVES_ = 0>
 struct GemmWSCfg {
   static constexpr int BM = BM_, BN = 128, WM = BM / 64, WN = 2, NCONS = WM * WN, NPROD = NPROD_, NWAVE = NCONS + NPROD, NTHREAD = NWAVE * 64;
   static constexpr int NSTAGE = NSTAGE_, WG_PER_CU = WG_PER_CU_;
@@ -37,15 +37,18 @@ struct GemmWSCfg {
   static constexpr int QA = BM / 8, QB = BN / 8;         // DMA instructions (8 tile rows of 128 B each) per unit
   static constexpr int QPW = (QA + QB) / NPROD;          // per producer wave
   static constexpr int QAW = QA / NPROD;                 // of which the first QAW fetch A rows
-  static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * NWAVE + 3) / 4;
+  static constexpr int MIN_WAVES_PER_SIMD = FORCE_WAVES_ ? FORCE_WAVES_ : (WG_PER_CU * NWAVE + 3) / 4;
   static_assert(QA % NPROD == 0 && QB % NPROD == 0 && (NSTAGE - 1) * QPW <= 63, "the DMA in flight must fit the vmcnt range");
   static_assert(WG_PER_CU * SMEM_TOTAL <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 3, "LDS budget / ring depth");
 };
 // 256 x 128 tiles, one workgroup per CU: 8 consumers + 2 producers, 3 x 48 KiB ring (+ 16 KiB bias)
 using GemmWS = GemmWSCfg<256, 2, 3, 1, 4096>;
 // (Measured and rejected, profiles/r03_gemm_ws_pair.txt: 128 x 128 tiles on TWO workgroups per CU -- GemmWSCfg<128, 1, 2, 2, 3072>, 4 consumers +
-// 1 producer each, so that one workgroup's epilogue sits under the other's MFMAs.  76 KiB per workgroup only leaves a 2-stage ring, which
-// exposes the DMA latency on every k-tile: 500 TF/s on QKV against 690 for the configuration above.)
+// 1 producer each (also 2 producers; also forced to 128 VGPRs), so that one workgroup's epilogue sits under the other's MFMAs.  76 KiB per
+// workgroup only leaves a 2-stage ring, which exposes the DMA latency on every k-tile: a lone 128 x 128 workgroup needs 0.77 us per k-tile
+// where the 256 x 128 one needs 0.84 for twice the work, and two of them per CU do not make up for it (QKV 55-68 us against 47-49; fc2, one
+// tile per workgroup and every workgroup resident: 65 us against 42).  About a third of the second workgroups also started only when a first
+// one had left (entry / exit stamps on the chip-wide clock), although the occupancy API reports 2 per CU.)
 
 // LDS row v of the Bt tile (0..127) holds tile row perm(v): within each 64-row block (one consumer column group), fragment row
 // i = v & 15 of column tile nt = (v >> 4) & 3 is weight row 16 (i >> 2) + 4 nt + (i & 3).  With the MFMA operands swapped
@@ -200,6 +203,14 @@ __device__ __forceinline__ const float* ws_bias(const EpiResidual& e) { return e
 __device__ __forceinline__ const float* ws_bias(const EpiGelu& e) { return e.bias; }
 template <class E> __device__ __forceinline__ const float* ws_bias(const E&) { return nullptr; }
 
+// chip-wide constant 100 MHz clock (measurement hook only): comparable across workgroups, unlike s_memtime
+__device__ __forceinline__ unsigned long long ws_realtime() {
+#ifdef APH_EMU
+  return 0ull;
+#else
+  return __builtin_amdgcn_s_memrealtime();
+#endif
+}
 // shader clock (measurement hook only)
 __device__ __forceinline__ unsigned long long ws_clock() {
 #ifdef APH_EMU
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     tile = start + b / G;
   }
   if (tile >= tile_end) return;                  // (workgroup-uniform; does not happen with gridDim.x <= ntiles)
+  if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 15) * 4 + 3] = ws_realtime();   // kernel entry, chip-wide 100 MHz clock
   const int nk = K / GEMM_BK, ntn = N / C::BN;
   const int U = ((tile_end - tile + tile_step - 1) / tile_step) * nk;       // k-tile units of this workgroup
   // the epilogue's bias vector goes to LDS behind the ring once (N <= 4096 floats); visible after the first barrier
@@ -342,6 +354,7 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
       if (u + 1 < U) init_tile(tile);
     }
   }
+  if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 14) * 4 + 3] = ws_realtime();     // consumer wave 0 done
 }
 
 template <class C, class Epi>
@@ -351,6 +364,13 @@ inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int l
   const int cus = gemm8_persistent_wgs();
   const int wgs = cus > (1 << 20) ? cus : cus * C::WG_PER_CU;
   APH_ALLOW_SMEM((gemm_ws_kernel<C, Epi>), C::SMEM_TOTAL);
+#ifndef APH_EMU
+  if (getenv("APH_WS_OCC")) {       // (experiment aid) what the runtime says about residency
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_ws_kernel<C, Epi>, C::NTHREAD, C::SMEM_TOTAL);
+    fprintf(stderr, "gemm_ws_kernel<BM %d>: occupancy API says %d workgroup(s) per CU (threads %d, LDS %d)\n", C::BM, nb, C::NTHREAD, C::SMEM_TOTAL);
+  }
+#endif
   APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles, trace);
 }
 template <class Epi>

@@ -196,6 +196,10 @@ class Engine:
                     if t is not None:
                         t.zero_()
                 self._state['step'][0] = 0
+                # skipped-step bookkeeping belongs to the optimiser instance that just ended: a skip reported (up to GUARD_EVERY steps
+                # late) after this point must not be subtracted from the NEW frame's step counter.  The device counter keeps counting
+                # (bench.py reads it); what is re-based is the host's view of it.
+                self._guard_rebase = True
 
     def set_prev_enc(self, enc_rows=None, active=True):
         """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
@@ -368,9 +372,12 @@ class Engine:
             self._guard_ev = torch.cuda.Event()
             self._guard_ev.record()
         if count > self._guard_seen:
-            # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either
-            self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
+            # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either (not carried across a
+            # reset_params: those skips belonged to the previous frame's optimiser)
+            if not getattr(self, '_guard_rebase', False):
+                self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
             self._guard_seen = count
+            self._guard_rebase = False
             self.loss_scale = max(self.loss_scale * 0.5, 1.0)
             self._graphs = None
             print(' fp16 overflow in the backward pass: %d step(s) skipped so far, loss scale -> %g' % (count, self.loss_scale), flush=True)

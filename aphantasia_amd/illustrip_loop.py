@@ -62,7 +62,7 @@ class FrameLoop:
             new = ops.rfft2(e.plan, img.reshape(3, self.h, self.w).contiguous(), out=self._spec, lib=e.lib)    # :407-408
         e.reset_params(new, keep_optimizer_state=self.smooth and self.frames > 0)
 
-    def frame(self, scale=1.012, shift=(0, 10.0), angle=0.8, shear=0.4, contrast=None, lr=None, noise=0.0):
+    def frame(self, scale=1.012, shift=(0, 10.0), angle=0.8, shear=0.4, contrast=None, lr=None, noise=0.0, consume_noise_draw=False):
         """One frame.  Defaults = illustrip's non-animated motion (`1 + a.scale`, `[0, a.shift]`, a.angle, a.shear with the CLI
         defaults, illustrip.py:70-73,381-384).  Returns the frame to save (device [3,h,w] in (0,1)) when `contrast` is given."""
         self.reparameterise(scale, shift, angle, shear)
@@ -70,6 +70,10 @@ class FrameLoop:
             ii = self.frames                     # `ii in dualmod_nums` (illustrip.py:372): every dualmod-th frame of the line
             e = self.eng2 if (self.eng2 is not None and self.dualmod and ii >= self.dualmod and ii % self.dualmod == 0) else self.eng
             sh = None
+            if consume_noise_draw:
+                # illustrip.py:429 draws torch.rand(1,1,H,W//2+1,1) on every step whenever a.noise > 0, also for --gen RGB where
+                # pixel_image ignores it: a seeded `--rng reference` run must consume it to stay on the reference's crop / augment stream
+                torch.rand(1, 1, self.h, self.w // 2 + 1, 1)
             if noise > 0 and self.gen == 'FFT':                                                             # illustrip.py:429
                 sh = (noise * (torch.rand(self.h, self.w // 2 + 1) - 0.5)).to(e.dev).contiguous()
             e.step(lr=lr, shift=sh)

@@ -165,8 +165,8 @@ def main(argv=None):
                 out.append((aclip.text_embedding(m, sub), sign * wt))
         return out
     trf = transforms.transforms_fast if a.transform == 'fast' else transforms.normalize()
-    if a.gen == 'RGB':                                                                          # illustrip.py:270-276: pixel_image([1,3,*size], sd=1) * 0.3-ish start
-        leaf = (torch.randn(1, 3, h, w) * 0.3).cuda().contiguous()
+    if a.gen == 'RGB':                                                                          # illustrip.py:270-272: pixel_image([1,3,*size], resume) -> randn * sd, sd = 1 (image.py:98-101)
+        leaf = torch.randn(1, 3, h, w).cuda().contiguous()
         pk = dict(param_kind='pixel', rgb_priors=True, fixcontrast=a.fixcontrast, decay=1.0)
     else:
         leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).cuda().contiguous()
@@ -190,7 +190,7 @@ def main(argv=None):
     t0 = time.time()
     for num in range(a.steps):
         img = loop.frame(1 + a.scale, [0, a.shift], a.angle, a.shear, contrast=None if writer is None else a.contrast,     # illustrip.py:381-384 (anima off)
-                         noise=a.noise if a.gen == 'FFT' else 0.0)
+                         noise=a.noise if a.gen == 'FFT' else 0.0, consume_noise_draw=(a.gen != 'FFT' and a.noise > 0 and a.rng == 'reference'))
         if writer is not None:
             writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%06d.jpg' % num), 1.0)
         if (a.verbose or world > 1) and (num % 10 == 9 or num == a.steps - 1):

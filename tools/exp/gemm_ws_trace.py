@@ -37,4 +37,12 @@ for (name, N, K, kind) in CASES:
         ok = valid[:, j]
         k0, ml, ep = t[ok, j, 0] * TICK, t[ok, j, 1] * TICK, t[ok, j, 2] * TICK
         line += ' t%d: k0@%.1f main+%.1f epi+%.1f (max %.1f) end@%.1f (max %.1f) |' % (j, k0.mean().item(), (ml - k0).mean().item(), (ep - ml).mean().item(), (ep - ml).max().item(), ep.mean().item(), ep.max().item())
+    # residency: entry / exit of every workgroup on the chip-wide 100 MHz clock -> how many are active at the same time
+    ent, ext = ti[:, 15, 3], ti[:, 14, 3]
+    t0_ = ent.min()
+    ent, ext = (ent - t0_).double() * 0.01, (ext - t0_).double() * 0.01
+    grid_t = torch.linspace(0, ext.max().item(), 200)
+    conc = ((ent[None, :] <= grid_t[:, None]) & (ext[None, :] > grid_t[:, None])).sum(1)
+    line += ' WG entry: median %.1f us max %.1f us after the first; WG duration median %.1f us; max concurrent WGs %d of %d |' % (
+        ent.median().item(), ent.max().item(), (ext - ent).median().item(), int(conc.max()), nwg)
     print(line, flush=True)
