@@ -13,6 +13,9 @@
 // Adjoint of the crop/resize: deterministic GATHER over crops per image pixel (fixed summation
 // order s = 0..S-1, no atomics) so a given crop table gives bitwise-reproducible gradients.
 // Adjoint of the bilinear warps: gathers through the inverse maps (deterministic as well).
+#include <cstring>
+#include <cstdlib>
+
 #include "aph_device.h"
 #include "aph_host.h"
 
@@ -439,6 +442,222 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------
+// [r3] Crop / resize adjoint, SEPARABLE and row-block stationary (frames without wrap padding: --align uniform / central).
+//
+//   d img[oy + q][ox + p] += sum_i Wy[i -> q] * ( sum_j Wx[j -> p] * G[i][j] )        per cut, Wy / Wx = the per-cut 1-D tap tables
+//
+// The gather kernel above visits every (pixel, covering cut) pair with up to 16 gathers x 3 channels and is bound by that per-pair
+// skeleton (332 us at C2).  Here a workgroup owns RB image rows of ONE channel across the whole width, every thread owns CPT columns and
+// keeps their RB accumulators in registers.  The covering cuts are walked in index order (deterministic, no atomics) in batches of NBC:
+//   phase 0  the batch's cut boxes and their RB row-tap entries -> LDS
+//   phase 1  column pass: U[b][j][q] = sum_a wy[a] * G_b[i_a][j] for the RB rows and all `size` columns of each cut (coalesced along j;
+//            a gradient row is read by the 1-2 row blocks its taps land in, not once per pixel)
+//   phase 2  row pass: acc[q][x] += sum_b wx[b] * U[b][j_b][q], the RB rows of a column tap fetched as 16-byte LDS reads
+// Up-sampling cuts (cs < size: never at 1280x720) take the per-pixel generic path of the gather kernel.
+// ---------------------------------------------------------------------------------
+constexpr int ADJ_NBC = 8;          // cuts per batch (the launcher lowers it when LDS is short)
+template <int OUT>
+__device__ __forceinline__ int grad_col_of_off(int off, int p) {         // inverse of grad_colpart
+  if (is_patch<OUT>::v) {
+    const int lp = __ffs(p) - 1;
+    const int jp = ((off >> (2 * lp)) * 43) >> 7;      // / 3 for values < 128 (at most size / patch = 7 .. 14 patch columns)
+    return (jp << lp) + (off - jp * (3 << (2 * lp)));
+  }
+  return off;
+}
+
+template <int OUT, int RBQ, int CPT>
+__global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __restrict__ gout, float gscale, const int* __restrict__ table,
+                                                                 float* __restrict__ grgb, Geom g, const AdjEntry* __restrict__ tab, int maxcs,
+                                                                 int RB, int NBC, int dbg) {
+  constexpr int RBP = RBQ * 4, MAXV = 1024;
+  APH_DYN_SMEM(smem);
+  float* U = reinterpret_cast<float*>(smem);                                   // [NBC][size][RBP]
+  AdjEntry* ent = reinterpret_cast<AdjEntry*>(U + (size_t)NBC * g.size * RBP); // [NBC][RBP]
+  int* binfo = reinterpret_cast<int*>(ent + NBC * RBP);                        // [NBC][4] = s (-1: none), cs, ox, oy (cs < 0: generic cut)
+  int* vlist = binfo + NBC * 4;                                                // [MAXV]
+  int* vcount = vlist + MAXV;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c = blockIdx.y, y0 = blockIdx.x * RB;
+  const int rows = g.H - y0 < RB ? g.H - y0 : RB;
+  const int cchan = is_patch<OUT>::v ? g.patch * g.patch : g.size * g.size;
+  const int ccut = is_patch<OUT>::v ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
+  f32x4 acc[CPT][RBQ];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i)
+#pragma unroll
+    for (int k = 0; k < RBQ; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < NBC * g.size * RBP; i += nthr) U[i] = 0.f;              // (the padding rows q >= RB stay zero for good)
+  for (int vbase = 0; vbase < g.S; vbase += MAXV) {
+    // ---- ordered list of the cuts that touch this row block (wave 0, ballot compaction)
+    __syncthreads();
+    if (tid < 64) {
+      int count = 0;
+      const int vend = g.S - vbase < MAXV ? g.S - vbase : MAXV;
+      for (int v0 = 0; v0 < vend; v0 += 64) {
+        const int s = vbase + v0 + tid;
+        bool hit = false;
+        if (v0 + tid < vend) {
+          const int cs = table[3 * s], oy = table[3 * s + 2];
+          hit = oy < y0 + rows && oy + cs > y0;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) vlist[count + __popcll(m & ((1ull << tid) - 1ull))] = s;
+        count += __popcll(m);
+      }
+      if (tid == 0) *vcount = count;
+    }
+    __syncthreads();
+    const int nlist = *vcount;
+    for (int b0 = 0; b0 < nlist; b0 += NBC) {
+      // ---- phase 0: boxes and row entries of the batch
+      if (tid < NBC * RBP) {
+        const int b = tid / RBP, q = tid - b * RBP;
+        AdjEntry e;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { e.off[a] = 0; e.w[a] = 0.f; }
+        if (b0 + b < nlist) {
+          const int s = vlist[b0 + b];
+          const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+          const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
+          const bool generic = !(scale >= 1.0f);
+          if (q == 0) { binfo[4 * b] = s; binfo[4 * b + 1] = generic ? -cs : cs; binfo[4 * b + 2] = ox; binfo[4 * b + 3] = oy; }
+          const int yc = y0 + q - oy;
+          if (!generic && q < rows && yc >= 0 && yc < cs && yc < maxcs) e = tab[((size_t)s * 2) * maxcs + yc];
+        } else if (q == 0) binfo[4 * b] = -1;
+        ent[tid] = e;
+      }
+      __syncthreads();
+      // ---- phase 1: column pass into U[b][j][q]: one wave per (cut, row) pair, lanes across the cut's columns
+      const int nb = nlist - b0 < NBC ? nlist - b0 : NBC;
+      if (!(dbg & 1)) {
+        // two (cut, row) pairs per wave and trip, every gather of both issued before the first is used: the pass is bound by memory
+        // latency (a lone wave waiting for 4 loads per trip measured 340 us of a 540 us kernel)
+        const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6, npair = nb * RB;
+        constexpr int JT = 4;                                      // column trips of 64 lanes: size <= 256 (checked by the launcher)
+        for (int pq0 = wv; pq0 < npair; pq0 += 2 * nwv) {
+          float u[2][JT];
+          AdjEntry e[2];
+          size_t gb[2];
+          int bq[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int pq = pq0 + h * nwv;
+            const bool ok = pq < npair;
+            const int b = ok ? pq / RB : 0, q = ok ? pq - b * RB : 0;
+            bq[h][0] = ok ? b : -1; bq[h][1] = q;
+            e[h] = ent[b * RBP + q];
+            if (!ok) { e[h].w[0] = 0.f; e[h].w[1] = 0.f; e[h].w[2] = 0.f; e[h].w[3] = 0.f; }
+            gb[h] = (size_t)binfo[4 * b] * ccut + (size_t)c * cchan;
+          }
+          float v[2][JT][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < JT; ++m) {
+              const int j = lane + 64 * m;
+              const size_t gj = gb[h] + grad_colpart<OUT>(j < g.size ? j : 0, g.size, g.patch);
+#pragma unroll
+              for (int a = 0; a < 4; ++a) v[h][m][a] = (e[h].w[a] != 0.f && j < g.size) ? gload<OUT>(gout, gj + e[h].off[a]) : 0.f;
+            }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < JT; ++m) {
+              u[h][m] = 0.f;
+#pragma unroll
+              for (int a = 0; a < 4; ++a) u[h][m] += e[h].w[a] * v[h][m][a];
+              const int j = lane + 64 * m;
+              if (bq[h][0] >= 0 && j < g.size) U[((size_t)bq[h][0] * g.size + j) * RBP + bq[h][1]] = u[h][m];
+            }
+        }
+      }
+      __syncthreads();
+      // ---- phase 2: row pass, cuts in list order
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          const int x = i * nthr + tid;
+          if (x >= g.W) continue;
+          // four column-tap entries at a time (independent loads in flight together), then their accumulation in list order
+#pragma unroll
+          for (int bh = 0; bh < ADJ_NBC; bh += 4) {
+            if (bh >= nb) break;
+            AdjEntry ce[4];
+            int pcol[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const int b = bh + bb;
+              pcol[bb] = -1;
+              if (b < nb) {
+                const int s = binfo[4 * b], csx = binfo[4 * b + 1], p = x - binfo[4 * b + 2];
+                if (csx > 0 && p >= 0 && p < csx && p < maxcs) {
+                  pcol[bb] = p;
+                  ce[bb] = tab[((size_t)s * 2 + 1) * maxcs + p];
+                }
+              }
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              if (pcol[bb] < 0) continue;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                if (ce[bb].w[t] == 0.f) continue;
+                const float* up = U + ((size_t)(bh + bb) * g.size + grad_col_of_off<OUT>(ce[bb].off[t], g.patch)) * RBP;
+#pragma unroll
+                for (int k = 0; k < RBQ; ++k) acc[i][k] += ce[bb].w[t] * *reinterpret_cast<const f32x4*>(up + 4 * k);
+              }
+            }
+          }
+          // up-sampling cuts (cs < size; none at 1280x720): the per-pixel generic path of crop_resize_adjoint_kernel.  Kept out of the
+          // unrolled loop above (a loop the compiler does not unroll would index ce[] at run time and move it to scratch memory); the
+          // sum of such a cut is added after the batch's table-driven cuts -- a fixed order all the same.
+          for (int b = 0; b < nb; ++b) {
+            const int csx = binfo[4 * b + 1];
+            if (csx >= 0) continue;
+            const int s = binfo[4 * b], oy = binfo[4 * b + 3], cs = -csx, p = x - binfo[4 * b + 2];
+            if (p < 0 || p >= cs) continue;
+            const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
+            const size_t gb = (size_t)s * ccut + (size_t)c * cchan;
+#pragma unroll
+            for (int q = 0; q < RBP; ++q) {            // (fully unrolled: a run-time index into acc would move it to scratch memory)
+              const int yc = y0 + q - oy;
+              if (q >= rows || yc < 0 || yc >= cs) continue;
+              float sum = 0.f;
+              for (int ii = 0; ii < g.size; ++ii) {
+                const float wy = tap_weight(scale, ii, cs, yc);
+                if (wy == 0.f) continue;
+                for (int jj = 0; jj < g.size; ++jj) {
+                  const float wx = tap_weight(scale, jj, cs, p);
+                  if (wx == 0.f) continue;
+                  sum += wy * wx * gload<OUT>(gout, gb + grad_rowpart<OUT>(ii, g.size, g.patch) + grad_colpart<OUT>(jj, g.size, g.patch));
+                }
+              }
+              acc[i][q >> 2][q & 3] += sum;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float kc = OUT == APH_OUT_NCHW_RAW ? gscale : gscale / kClipStd[c];
+  const size_t HW = (size_t)g.H * g.W;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int x = i * nthr + tid;
+    if (x >= g.W) continue;
+#pragma unroll
+    for (int k = 0; k < RBQ; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 4 * k + r;
+        if (q < rows) grgb[(size_t)c * HW + (size_t)(y0 + q) * g.W + x] = acc[i][k][r] * kc;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // torchvision-style warps (grid_sample bilinear, zeros padding, align_corners=False, ones-mask fill 0)
 // ---------------------------------------------------------------------------------
 struct Tap {
@@ -760,10 +979,45 @@ void launch_crop_resize(const float* rgb, const int* table, void* out, const Geo
   APH_LAUNCH(crop_resize_strips_kernel<OUT>, dim3(8 * kStripSlots), dim3(256), 0, st, rgb, table, out, g, (const int*)lists, (const int*)counts, strip_cap(g));
 }
 
+// 1: always the round-2 gather kernel (environment APH_CROP_ADJOINT=gather, or aph_crop_adjoint_set_gather for A/B runs and tests)
+inline int& crop_adjoint_gather() {
+  static int v = [] { const char* e = getenv("APH_CROP_ADJOINT"); return (e && !strcmp(e, "gather")) ? 1 : 0; }();
+  return v;
+}
+
 template <int OUT>
 int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, AdjEntry* tab, hipStream_t st) {
   const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;
   APH_LAUNCH(tap_table_kernel<OUT>, dim3((maxcs + 127) / 128, 2, g.S), dim3(128), 0, st, table, tab, maxcs, g);
+  // [r3] frames without wrap padding: the separable row-block kernel (APH_CROP_ADJOINT=gather keeps the round-2 gather kernel for A/B runs)
+  if (!crop_adjoint_gather() && g.Hp == g.H && g.Wp == g.W && g.py0 == 0 && g.px0 == 0 && g.W <= 2304 && g.size <= 256) {
+    const int cpt = g.W <= 1536 ? 2 : 3;                      // columns per thread, at most 768 threads (three waves per SIMD: 168 VGPRs)
+    int nthr = (((g.W + cpt - 1) / cpt) + 63) / 64 * 64;
+    nthr = nthr < 256 ? 256 : nthr;
+    // rows per workgroup: about one workgroup per CU over rows x 3 channels (85 row blocks), 12 or 16 accumulator rows per column
+    int rb = (g.H + 84) / 85;
+    rb = rb < 4 ? 4 : (rb > 16 ? 16 : rb);
+    const int rbq = rb <= 12 ? 3 : 4, rbp = rbq * 4;
+    int nbc = ADJ_NBC;
+    auto lds = [&](int n) { return (size_t)n * g.size * rbp * 4 + (size_t)n * rbp * sizeof(AdjEntry) + (size_t)n * 16 + 1024 * 4 + 16; };
+    while (nbc > 1 && lds(nbc) > 150 * 1024) --nbc;
+    if (lds(nbc) <= 150 * 1024) {
+      const dim3 rgrid((g.H + rb - 1) / rb, 3);
+      static const int dbg = [] { const char* e = getenv("APH_SAMPLER_DBG"); return e ? atoi(e) : 0; }();     // (ablation: 1 = no column pass, 2 = no row pass)
+      const size_t smem = lds(nbc);
+#define APH_ADJ_ROWS(RBQ, CPT)                                                                                                              \
+  do {                                                                                                                                       \
+    APH_ALLOW_SMEM((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), 150 * 1024);                                                                   \
+    APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg); \
+  } while (0)
+      if (rbq == 3 && cpt == 2) APH_ADJ_ROWS(3, 2);
+      else if (rbq == 3) APH_ADJ_ROWS(3, 3);
+      else if (cpt == 2) APH_ADJ_ROWS(4, 2);
+      else APH_ADJ_ROWS(4, 3);
+#undef APH_ADJ_ROWS
+      return APH_OK;
+    }
+  }
   const dim3 agrid(8 * (((g.H + 15) / 16 + 7) / 8) * ((g.W + 15) / 16));        // 8 XCD shares of ceil(tile rows / 8) rows each (see the kernel's tile order)
   APH_LAUNCH(crop_resize_adjoint_kernel<OUT>, agrid, dim3(256), 0, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs);
   return APH_OK;
@@ -771,6 +1025,13 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
 }  // namespace
 
 extern "C" {
+
+// test / measurement hook: 1 = the crop adjoint always runs the gather kernel, 0 = automatic.  Returns the previous value.
+int aph_crop_adjoint_set_gather(int on) {
+  const int prev = crop_adjoint_gather();
+  crop_adjoint_gather() = on ? 1 : 0;
+  return prev;
+}
 
 size_t aph_sample_ws_bytes(const aph_sample_geom* gg, int with_aug) {
   if (!gg || gg->S < 1 || gg->size < 1 || gg->Hp < 1 || gg->Wp < 1) return 0;

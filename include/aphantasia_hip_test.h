@@ -35,6 +35,10 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg,
                     void* stream);
 
+/* Crop / resize adjoint of aph_sample_bwd: 1 = always the per-pixel gather kernel (round 2), 0 = automatic (the separable row-block kernel
+ * on frames without wrap padding).  Process-wide, returns the previous value; environment APH_CROP_ADJOINT=gather sets the initial value. */
+int aph_crop_adjoint_set_gather(int on);
+
 /* MFMA shape of the GEMM main loops launched from now on (process-wide): 0 = v_mfma_f32_16x16x32_f16 (default: measured
  * faster on MI355X with real operands -- the chip is power-limited there and the 32x32x16 form sustains less),
  * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */

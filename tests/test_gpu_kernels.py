@@ -98,6 +98,34 @@ def test_attention_alone_vs_torch():
         K.check_attention(None, DEV, S=3, T=T, heads=12, seed=T)
 
 
+def test_crop_adjoint_rows_kernel_vs_gather_kernel_full_size():
+    """[r3] the separable row-block crop adjoint (frames without wrap padding) against the round-2 per-pixel gather kernel at the headline
+    geometry (1280x720, 190 cuts, patch-major gradient; and the planar layout the -tf fast chain hands it), plus 4K width (4 columns per
+    thread); same bits on every launch"""
+    import numpy as np
+    import torch
+    from aphantasia_amd import ops
+    from aphantasia_amd.utils import draw_crop_params_bulk
+    L = _ffi.lib()
+    for (H, W, S, mode) in ((720, 1280, 190, _ffi.APH_OUT_PATCH_F16), (720, 1280, 48, _ffi.APH_OUT_NCHW_RAW), (2160, 3840, 24, _ffi.APH_OUT_PATCH_F16),
+                            (300, 500, 16, _ffi.APH_OUT_NCHW_NORM)):
+        rng = np.random.default_rng(H)
+        geom = ops.make_geom(H, W, S, 224, 32)
+        table, _ = draw_crop_params_bulk(S, 224, H, W, 'uniform', 0.4, None, rng)
+        tb = torch.from_numpy(table).to(DEV)
+        g = torch.randn(S * 49, 3072, device=DEV) if mode == _ffi.APH_OUT_PATCH_F16 else torch.randn(S, 3, 224, 224, device=DEV)
+        new = ops.sample_bwd(geom, g, tb, out_mode=mode, gscale=0.5).clone()
+        again = ops.sample_bwd(geom, g, tb, out_mode=mode, gscale=0.5)
+        assert torch.equal(new, again)
+        prev = L.cdll.aph_crop_adjoint_set_gather(1)
+        try:
+            old = ops.sample_bwd(geom, g, tb, out_mode=mode, gscale=0.5).clone()
+        finally:
+            L.cdll.aph_crop_adjoint_set_gather(prev)
+        err = (new - old).abs().max().item() / old.abs().max().item()
+        assert err < 2e-6, (H, W, S, mode, err)
+
+
 def test_attention_backward_is_deterministic():
     import torch
     a1, d1 = K.check_attention(None, DEV, S=190, T=50, heads=12)

@@ -139,6 +139,15 @@ def test_c2_loss_curve_200cuts_50steps_vs_oracle_fixture():
     assert rms < 0.02, rms
 
 
+def test_c2_loss_curve_200cuts_200steps_vs_oracle_fixture():
+    """BASELINE configs[1] VERBATIM (`--samples 200 --steps 200`, -tf none): the whole 200-step free-running curve against the oracle's
+    (tests/golden/loss_curve_c2_s200_200.npz: 45 minutes of host CPU, generated once)"""
+    worst, first, rms, _ = _curve('c2_s200_200')
+    print('C2 200 cuts, 200 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f' % (worst, first, rms))
+    assert first is None and worst < 1e-3, (worst, first)
+    assert rms < 0.03, rms
+
+
 def test_c2_loss_curve_32cuts_200steps_vs_oracle_fixture():
     """BASELINE configs[1]'s step count (--steps 200) at 32 cuts: the curve stays inside 1e-3 over the whole run"""
     worst, first, rms, _ = _curve('c2_s32')

@@ -35,4 +35,8 @@ for name, trf in (('none', transforms.normalize()), ('fast', transforms.transfor
     grgb = torch.empty(3, H, W, device=dev)
     f = lambda: ops.sample_fwd(geom, img, tb, ag, ws, out, _ffi.APH_OUT_PATCH_F16)
     b = lambda: ops.sample_bwd(geom, g, tb, ag, ws, grgb, _ffi.APH_OUT_PATCH_F16)
-    print('-tf %-5s S=%d %dx%d dbg=%s: forward %7.1f us   adjoint %7.1f us' % (name, S, W, H, os.environ.get('APH_SAMPLER_DBG', '0'), timeit(f), timeit(b)), flush=True)
+    tb_new = timeit(b)
+    prev = _ffi.lib().cdll.aph_crop_adjoint_set_gather(1)
+    tb_old = timeit(b)
+    _ffi.lib().cdll.aph_crop_adjoint_set_gather(prev)
+    print('-tf %-5s S=%d %dx%d dbg=%s: forward %7.1f us   adjoint %7.1f us  (with the round-2 gather crop adjoint: %7.1f us)' % (name, S, W, H, os.environ.get('APH_SAMPLER_DBG', '0'), timeit(f), tb_new, tb_old), flush=True)
