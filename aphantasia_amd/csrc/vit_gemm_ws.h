@@ -13,9 +13,9 @@
 //     registers: their vmcnt counts only epilogue traffic and the main loop never waits on it, so the stores of tile i
 //     drain while tile i + 1 is being multiplied, and the operands of tile i + 1 are already in LDS when tile i ends.
 //   * No LDS staging in the epilogue: the rows of the Bt tile are PERMUTED on their way into LDS (the DMA source address
-//     is per lane, so this is free) such that the 4 x 4 accumulator registers a lane holds for one output row are 16
-//     CONSECUTIVE columns: a lane stores 32 (f16) / 64 (f32) contiguous bytes per row, the four lanes of a row one or
-//     two whole 128-byte lines.  The ring is never idle, no workgroup barrier separates main loop and epilogue.
+//     is per lane, so this is free) such that a lane's accumulator registers are four consecutive columns of four rows and the 16
+//     lanes l & 15 hold a row's 64 columns in order: stores leave as whole rows from adjacent lanes (gemm_ws_brow).  The ring is
+//     never idle, no workgroup barrier separates main loop and epilogue.
 // One s_barrier per k-tile, shared by all ten waves (the protocol of the ring kernels in vit_gemm.h):
 //   producers: DMA of unit u+1 landed (counted vmcnt, unit u+2 stays in flight) -> barrier -> issue unit u+3 into the
 //              stage unit u just vacated;
@@ -51,151 +51,112 @@ using GemmWS = GemmWSCfg<256, 2, 3, 1, 4096>;
 // one had left (entry / exit stamps on the chip-wide clock), although the occupancy API reports 2 per CU.)
 
 // LDS row v of the Bt tile (0..127) holds tile row perm(v): within each 64-row block (one consumer column group), fragment row
-// i = v & 15 of column tile nt = (v >> 4) & 3 is weight row 16 (i >> 2) + 4 nt + (i & 3).  With the MFMA operands swapped
-// (weights as the A fragment) lane l, register r of acc[mt][nt] is then column 16 (l >> 4) + 4 nt + r of row l & 15.
+// i = v & 15 of column tile nt = (v >> 4) & 3 is weight row 4 i + nt.  The MFMAs take the TOKENS as their A fragment and the weights
+// as B (vit_gemm.h does it the other way round for its LDS-staged epilogue), so lane l, register r of acc[mt][nt] is
+//     row  16 mt + 4 (l >> 4) + r ,   column  4 (l & 15) + nt        of the wave's 64 x 64 tile:
+// for a fixed (mt, r) a lane holds FOUR CONSECUTIVE columns (nt = 0..3) and the 16 lanes l & 15 = 0..15 hold the row's 64 columns in order.
+// A store instruction therefore writes whole rows from ADJACENT lanes (16 lanes x 8 B = one 128-byte line of f16, x 16 B = two lines of
+// f32; four rows per instruction), which is what the address coalescer wants: the first version of this epilogue kept the weights-as-A
+// order, gave a lane 16 consecutive columns and exchanged pieces among lanes 16 apart (v_permlane16/32_swap) -- its stores were 64
+// contiguous bytes per row, but from lanes 16 apart, and issued at a quarter of the store path's rate (15 B/clk per CU by the per-tile
+// trace, profiles/r03_gemm_ws_trace.txt; the lane mapping of the swaps is probed by tools/exp/permlane_probe.hip).
 __host__ __device__ __forceinline__ int gemm_ws_brow(int v) {
   const int vv = v & 63, nt = vv >> 4, i = vv & 15;
-  return (v & ~63) + ((i >> 2) << 4) + (nt << 2) + (i & 3);
+  return (v & ~63) + (i << 2) + nt;
 }
 
-
-// ---- register transposes among the four lanes that hold one output row (lanes j, j + 16, j + 32, j + 48) -------------
-// v_permlane16_swap: rows (16 lanes) 1 and 3 of `a` trade places with rows 0 and 2 of `b`; v_permlane32_swap: the upper 32 lanes
-// of `a` with the lower 32 lanes of `b` (gfx950; semantics probed on hardware by tools/exp/permlane_probe.hip).
-__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
-#ifdef APH_EMU
-  const int l = emu::lane_id();
-  const unsigned b_prev = __shfl(b, (l - 16) & 63), a_next = __shfl(a, (l + 16) & 63);
-  if ((l >> 4) & 1) a = b_prev; else b = a_next;
-#else
-  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-  a = r[0]; b = r[1];
-#endif
-}
-__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
-#ifdef APH_EMU
-  const int l = emu::lane_id();
-  const unsigned b_prev = __shfl(b, (l - 32) & 63), a_next = __shfl(a, (l + 32) & 63);
-  if (l >= 32) a = b_prev; else b = a_next;
-#else
-  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0]; b = r[1];
-#endif
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <bool S32, class V>
-__device__ __forceinline__ void swap_regs4(V& a, V& b) {       // V: any 16-byte register quad
-  u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    unsigned p = x[c], q = y[c];
-    if (S32) swap32(p, q); else swap16(p, q);
-    x[c] = p; y[c] = q;
-  }
-  a = __builtin_bit_cast(V, x); b = __builtin_bit_cast(V, y);
-}
-// in: lane group g (= lane >> 4) holds pieces 4g .. 4g+3 of its row's 16 four-column pieces;  out: v[q] = piece 4q + g
-// (store instruction q then writes 64 contiguous bytes per row).  Its own inverse.
-__device__ __forceinline__ void xpose4(f32x4 (&v)[4]) {
-  swap_regs4<false>(v[0], v[1]); swap_regs4<false>(v[2], v[3]);
-  swap_regs4<true>(v[0], v[2]); swap_regs4<true>(v[1], v[3]);
-}
-// in: lane group g holds pieces 2g, 2g+1 of its row's 8 eight-column f16 pieces;  out: p_q = piece 4q + g.  xpose2_inv undoes it.
-__device__ __forceinline__ void xpose2(half8& p0, half8& p1) { swap_regs4<false>(p0, p1); swap_regs4<true>(p0, p1); }
-__device__ __forceinline__ void xpose2_inv(half8& p0, half8& p1) { swap_regs4<true>(p0, p1); swap_regs4<false>(p0, p1); }
-
-__device__ __forceinline__ half8 pack_h8(const f32x4& a, const f32x4& b) {
-  return half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
-}
-__device__ __forceinline__ void st_h8(half_t* p, const half8& h) { *reinterpret_cast<half8*>(p) = h; }
+__device__ __forceinline__ half4 pack_h4(float a, float b, float c, float d) { return half4{(half_t)a, (half_t)b, (half_t)c, (half_t)d}; }
 
 // ---- epilogues of the wave-specialised kernel ------------------------------------------------------------------------
-// ws_row(epi, m, ok, nw, g, v, lb): v = the 16 consecutive columns nw + 16 g .. + 15 of output row m held by this lane (ok = row
-// exists; every lane of the wave must call, the transposes are wave collectives); lb = this GEMM's bias vector in LDS (or null).
-// Stores leave as 16-byte pieces, 64 contiguous bytes per row and instruction.
-__device__ __forceinline__ void ws_add_bias16(f32x4 (&v)[4], const float* lb, int n) {
+// ws_tile(epi, m4, M, n4, v, lb): v[nt][r] = C[m4 + r][n4 + nt], r = 0..3 (four rows: m4 = tile row base + 4 (l >> 4)), nt = 0..3 (four
+// consecutive columns: n4 = wave column base + 4 (l & 15)); lb = this GEMM's bias vector in LDS (or null).  Rows >= M are not stored.
+#define APH_WS_ROWS(r, m4, M) for (int r = 0; r < 4; ++r) if ((m4) + r < (M))
+__device__ __forceinline__ void ws_tile(const EpiF16& e, int m4, int M, int n4, f32x4 (&v)[4], const float* lb) {
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) b = *reinterpret_cast<const f32x4*>(lb + n4);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] += *reinterpret_cast<const f32x4*>(lb + n + 4 * i);
+  APH_WS_ROWS(r, m4, M)
+    *reinterpret_cast<half4*>(e.out + (size_t)(m4 + r) * e.ldo + n4) = pack_h4(v[0][r] + b[0], v[1][r] + b[1], v[2][r] + b[2], v[3][r] + b[3]);
 }
-__device__ __forceinline__ void ws_store_h16(half_t* row, int nw, int g, bool ok, const f32x4 (&v)[4]) {
-  half8 p0 = pack_h8(v[0], v[1]), p1 = pack_h8(v[2], v[3]);
-  xpose2(p0, p1);
-  if (ok) { st_h8(row + nw + 8 * g, p0); st_h8(row + nw + 32 + 8 * g, p1); }
-}
-__device__ __forceinline__ void ws_row(const EpiF16& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float* lb) {
-  if (e.bias) ws_add_bias16(v, lb, nw + 16 * g);
-  ws_store_h16(e.out + (size_t)m * e.ldo, nw, g, ok, v);
-}
-__device__ __forceinline__ void ws_row(const EpiF16Scale& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
+__device__ __forceinline__ void ws_tile(const EpiF16Scale& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] *= e.scale;
-  ws_store_h16(e.out + (size_t)m * e.ldo, nw, g, ok, v);
+  APH_WS_ROWS(r, m4, M)
+    *reinterpret_cast<half4*>(e.out + (size_t)(m4 + r) * e.ldo + n4) = pack_h4(v[0][r] * e.scale, v[1][r] * e.scale, v[2][r] * e.scale, v[3][r] * e.scale);
 }
-__device__ __forceinline__ void ws_row(const EpiF32& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
-  xpose4(v);
-  if (ok) {
-    float* o = e.out + (size_t)m * e.ldo + nw + 4 * g;
+__device__ __forceinline__ void ws_tile(const EpiF32& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st4(o + 16 * q, v[q] * e.scale);
-  }
+  APH_WS_ROWS(r, m4, M) st4(e.out + (size_t)(m4 + r) * e.ldo + n4, f32x4{v[0][r], v[1][r], v[2][r], v[3][r]} * e.scale);
 }
-__device__ __forceinline__ void ws_row(const EpiNoStore& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
+__device__ __forceinline__ void ws_tile(const EpiNoStore& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
   const f32x4 t = v[0] + v[1] + v[2] + v[3];            // every accumulator stays live
-  if (ok && t[0] + t[1] + t[2] + t[3] == 1.2345678e33f) st4(e.out + (size_t)m * e.ldo + nw + 16 * g, t);
+  if (m4 < M && t[0] + t[1] + t[2] + t[3] == 1.2345678e33f) st4(e.out + (size_t)m4 * e.ldo + n4, t);
 }
-__device__ __forceinline__ void ws_row(const EpiResidual& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
-  // residual and bias are already in the accumulators (ws_init below): transpose and store
-  xpose4(v);
-  if (ok) {
-    float* o = e.out + (size_t)m * e.ldo + nw + 4 * g;
+__device__ __forceinline__ void ws_tile(const EpiResidual& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
+  // residual and bias are already in the accumulators (ws_init below): store only
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st4(o + 16 * q, v[q]);
+  APH_WS_ROWS(r, m4, M) st4(e.out + (size_t)(m4 + r) * e.ldo + n4, f32x4{v[0][r], v[1][r], v[2][r], v[3][r]});
+}
+__device__ __forceinline__ void ws_tile(const EpiPatchEmbed& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
+#pragma unroll
+  APH_WS_ROWS(r, m4, M) {
+    const int m = m4 + r, s = m / e.P, p = m - s * e.P;
+    st4(e.x0 + ((size_t)s * e.T + 1 + p) * e.D + n4, f32x4{v[0][r], v[1][r], v[2][r], v[3][r]} + ld4(e.pos + (size_t)(1 + p) * e.D + n4));
   }
 }
-__device__ __forceinline__ void ws_row(const EpiPatchEmbed& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
-  xpose4(v);
-  if (ok) {
-    const int s = m / e.P, p = m - s * e.P;
-    const float* pe = e.pos + (size_t)(1 + p) * e.D + nw + 4 * g;
-    float* o = e.x0 + ((size_t)s * e.T + 1 + p) * e.D + nw + 4 * g;
+__device__ __forceinline__ void ws_tile(const EpiGelu& e, int m4, int M, int n4, f32x4 (&v)[4], const float* lb) {
+  const f32x4 b = *reinterpret_cast<const f32x4*>(lb + n4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st4(o + 16 * q, v[q] + ld4(pe + 16 * q));
+  for (int r = 0; r < 4; ++r) {
+    f32x4 gl, dg;
+    quick_gelu4(f32x4{v[0][r] + b[0], v[1][r] + b[1], v[2][r] + b[2], v[3][r] + b[3]}, gl, dg);
+    if (m4 + r < M) {
+      *reinterpret_cast<half4*>(e.g + (size_t)(m4 + r) * e.ldo + n4) = pack_h4(gl[0], gl[1], gl[2], gl[3]);
+      *reinterpret_cast<half4*>(e.dg + (size_t)(m4 + r) * e.ldo + n4) = pack_h4(dg[0], dg[1], dg[2], dg[3]);
+    }
   }
 }
-__device__ __forceinline__ void ws_row(const EpiGelu& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float* lb) {
-  ws_add_bias16(v, lb, nw + 16 * g);
-  f32x4 gl[4], dg[4];
+__device__ __forceinline__ void ws_tile(const EpiGeluBwd& e, int m4, int M, int n4, f32x4 (&v)[4], const half4 (&d)[4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) quick_gelu4(v[i], gl[i], dg[i]);
-  ws_store_h16(e.g + (size_t)m * e.ldo, nw, g, ok, gl);
-  ws_store_h16(e.dg + (size_t)m * e.ldo, nw, g, ok, dg);
+  APH_WS_ROWS(r, m4, M)
+    *reinterpret_cast<half4*>(e.out + (size_t)(m4 + r) * e.ldo + n4) =
+        pack_h4(v[0][r] * (float)d[r][0], v[1][r] * (float)d[r][1], v[2][r] * (float)d[r][2], v[3][r] * (float)d[r][3]);
 }
-__device__ __forceinline__ void ws_row(const EpiGeluBwd& e, int m, bool ok, int nw, int g, f32x4 (&v)[4], const float*) {
-  // dg/du is read in the store pattern (64 contiguous bytes per row and instruction) and moved back to the accumulators' columns
-  half8 d0 = {}, d1 = {};
-  if (ok) {
-    const half_t* d = e.dg + (size_t)m * e.ldo + nw + 8 * g;
-    d0 = *reinterpret_cast<const half8*>(d);
-    d1 = *reinterpret_cast<const half8*>(d + 32);
-  }
-  xpose2_inv(d0, d1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { v[0][i] *= (float)d0[i]; v[1][i] *= (float)d0[4 + i]; v[2][i] *= (float)d1[i]; v[3][i] *= (float)d1[4 + i]; }
-  ws_store_h16(e.out + (size_t)m * e.ldo, nw, g, ok, v);
-}
-// ws_init: the accumulators' starting value for output row m (same arguments as ws_row).  The residual epilogue starts them from
-// res + bias, read in the store pattern (64 contiguous bytes per row and instruction) and transposed into the MFMA layout: the
-// loads' latency hides behind the tile's first DMA wait instead of sitting between main loop and stores.
+#undef APH_WS_ROWS
+// the whole 64 x 64 wave tile: acc[mt] is the 16-row block at m4 + 16 mt
 template <class E>
-__device__ __forceinline__ void ws_init(const E&, int, int, int, int, f32x4 (&v)[4], const float*) {
+__device__ __forceinline__ void ws_tiles(const E& e, int m4, int M, int n4, f32x4 (&acc)[4][4], const float* lb) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ws_tile(e, m4 + mt * 16, M, n4, acc[mt], lb);
+}
+// QuickGELU backward reads dg/du: every load of the tile is issued before the first store (the compiler cannot prove that `out` and `dg`
+// do not alias; interleaved, each row's load would be waited for between two stores: 88 instead of 70 us per launch)
+__device__ __forceinline__ void ws_tiles(const EpiGeluBwd& e, int m4, int M, int n4, f32x4 (&acc)[4][4], const float*) {
+  half4 d[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m4 + mt * 16 + r;
+      d[mt][r] = *reinterpret_cast<const half4*>(e.dg + (size_t)(m < M ? m : M - 1) * e.ldo + n4);       // (rows past M: clamped read, never stored)
+    }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ws_tile(e, m4 + mt * 16, M, n4, acc[mt], d[mt]);
+}
+// ws_init: the accumulators' starting value (same arguments as ws_tile).  The residual epilogue starts them from res + bias: the loads'
+// latency hides behind the tile's first DMA wait instead of sitting between main loop and stores.
+template <class E>
+__device__ __forceinline__ void ws_init(const E&, int, int, int, f32x4 (&v)[4], const float*) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void ws_init(const EpiResidual& e, int m, int M, int nw, int g, f32x4 (&v)[4], const float* lb) {
-  const float* r = e.res + (size_t)(m < M ? m : M - 1) * e.ldo + nw + 4 * g;       // (rows past M: clamped read, never stored)
+__device__ __forceinline__ void ws_init(const EpiResidual& e, int m4, int M, int n4, f32x4 (&v)[4], const float* lb) {
+  const f32x4 b = *reinterpret_cast<const f32x4*>(lb + n4);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = ld4(r + 16 * q) + *reinterpret_cast<const f32x4*>(lb + nw + 4 * g + 16 * q);
-  xpose4(v);
+  for (int r = 0; r < 4; ++r) {
+    const int m = m4 + r < M ? m4 + r : M - 1;                      // (rows past M: clamped read, never stored)
+    const f32x4 x = ld4(e.res + (size_t)m * e.ldo + n4) + b;
+    v[0][r] = x[0]; v[1][r] = x[1]; v[2][r] = x[2]; v[3][r] = x[3];
+  }
 }
 // the bias vector an epilogue wants staged in LDS (nullptr: none)
 __device__ __forceinline__ const float* ws_bias(const EpiF16& e) { return e.bias; }
@@ -319,9 +280,15 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   wait_vm_barrier<63>();                                                       // unit 0 has landed (and the bias vector is in LDS)
   auto init_tile = [&](int t) {
     const int tm = t / ntn;
-    const int mrow = tm * C::BM + wm * 64 + (lane & 15), nw = (t - tm * ntn) * C::BN + wn * 64;
+    const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = (t - tm * ntn) * C::BN + wn * 64 + 4 * (lane & 15);
 #pragma unroll
-    for (int mt = 0; mt < F::TM; ++mt) ws_init(epi, mrow + mt * 16, M, nw, lane >> 4, acc[mt], lbias);
+    for (int mt = 0; mt < F::TM; ++mt) ws_init(epi, m4 + mt * 16, M, n4, acc[mt], lbias);
+  };
+  auto mma = [&](const GemmFrags<F>& f) {                                    // tokens as the A fragment: D rows = token rows
+#pragma unroll
+    for (int mt = 0; mt < F::TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < F::TN; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f.a[mt], f.b[nt], acc[mt][nt]);
   };
   init_tile(tile);
   gemm_load_frags<F>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
@@ -329,25 +296,21 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     const half_t* As = lds + st * C::STAGE;
     st = st == C::NSTAGE - 1 ? 0 : st + 1;
     gemm_load_frags<F>(f1, As, As + C::BM * GEMM_BK, arow, brow, 4 + fchunk);  // k-step 1 of unit u: in flight during the MFMAs
-    gemm_mma<F>(acc, f0);                                                      // k-step 0 of unit u
+    mma(f0);                                                                   // k-step 0 of unit u
     if (u + 1 < U) {
       wait_lgkm0();                                                            // f1 has left LDS: the stage of unit u is dead for this wave
       wait_vm_barrier<63>();                                                   // (vmcnt(63): this wave's stores are never waited for here)
       const half_t* An = lds + st * C::STAGE;
       gemm_load_frags<F>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);    // k-step 0 of unit u+1: overlaps the MFMAs below
     }
-    gemm_mma<F>(acc, f1);                                                      // k-step 1 of unit u
+    mma(f1);                                                                   // k-step 1 of unit u
     if (trace && kt == 0 && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 0] = ws_clock();      // first k-tile of a tile done
     if (++kt == nk) {
       if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 1] = ws_clock();                // main loop done
-      // epilogue straight from the accumulators: row l & 15 of each 16-row tile, 16 consecutive columns at 16 (l >> 4)
+      // epilogue straight from the accumulators (layout: gemm_ws_brow above)
       const int tm = tile / ntn;
-      const int mrow = tm * C::BM + wm * 64 + (lane & 15), nw = (tile - tm * ntn) * C::BN + wn * 64;
-#pragma unroll
-      for (int mt = 0; mt < F::TM; ++mt) {
-        const int m = mrow + mt * 16;
-        ws_row(epi, m, m < M, nw, lane >> 4, acc[mt], lbias);
-      }
+      const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = (tile - tm * ntn) * C::BN + wn * 64 + 4 * (lane & 15);
+      ws_tiles(epi, m4, M, n4, acc, lbias);
       if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 2] = ws_clock();                // epilogue issued
       kt = 0;
       tile += tile_step;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full validation of one build: GPU test suite, bench line per config, kernel-trace summary, FETCH/WRITE PMC passes -> profiles-ready files
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
@@ -26,7 +26,7 @@ for f in $O/${TAG}_bench_c*.json; do python - "$f" <<'PY'
 import json,sys
 try:
     j=json.load(open(sys.argv[1])); r=j['roofline'] or {}
-    print('%-34s %.1f steps/s gemm %.3f ms %.0f TF/s frac %.3f step_frac %.3f skipped %s stale %s %s' % (sys.argv[1].split('/')[-1], j['value'], r.get('gemm_ms_per_step', 0), r.get('achieved', 0), r.get('frac', 0), r.get('step_frac', 0), j['config'].get('skipped_steps'), r.get('traffic_stale'), {k: round(v['value'], 1) for k, v in (j.get('legs') or {}).items()}))
+    print('%-34s %.1f steps/s gemm %.3f ms %.0f TF/s frac %.3f step_frac %.3f skipped %s stale %s %s' % (sys.argv[1].split('/')[-1], j['value'], r.get('gemm_ms_per_step', 0), r.get('achieved', 0), r.get('frac', 0), r.get('step_frac', 0), j['config'].get('skipped_steps'), r.get('traffic_stale'), {k: round(v['value'], 1) for k, v in (j.get('legs') or {}).items() if 'value' in v}))
 except Exception as e: print(sys.argv[1], 'failed', e)
 PY
 done
