@@ -195,7 +195,11 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   APH_DYN_SMEM(smem);
   half_t* lds = reinterpret_cast<half_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  // persistent tile run (as gemm8_f16_kernel): XCD x owns one contiguous run of tiles, n-tiles fastest; its workgroups walk it
+  // persistent tile run (as gemm8_f16_kernel): XCD x owns one contiguous run of tiles, n-tiles fastest; its workgroups walk it.
+  // (Measured and rejected: a RECTANGLE of the tile grid per XCD -- a quarter of the row panels x half of the column tiles -- so that an
+  // XCD's share of the weights stays in its L2 instead of being re-fetched per row panel (284 MB of fabric traffic per fc1 launch for 136 MB
+  // algorithmic).  Slower everywhere: fc1 58.3 vs 53.8 us, QKV 43.5 vs 42.0, and the single-round N = 768 shapes lose their one-tile-per-
+  // workgroup balance (fc2 73.6 vs 44.4 us).  The re-fetches are served by the 256 MiB Infinity Cache and are not what bounds these launches.)
   int tile, tile_end, tile_step;
   {
     const int nwg = gridDim.x, b = blockIdx.x, G = nwg < 8 ? nwg : 8;
