@@ -170,6 +170,36 @@ def test_augment_oracle_invariants():
     assert abs(float(r[0, 0, n // 2, n // 2]) - 1.0) < 1e-6
 
 
+def test_augment_geometry_vs_pil_float_transforms():
+    """a-8 / f-1 without torchvision: the restated tensor-path maths (oracle/augment_ref.py: perspective coefficients, inverse affine
+    matrix, base grids, bilinear grid_sample) against an INDEPENDENT implementation that IS executable here -- Pillow's own float ('F' mode)
+    `Image.transform(PERSPECTIVE / AFFINE, BILINEAR)`, i.e. what torchvision's PIL backend calls with the same coefficient helpers
+    (`F_pil.perspective` / `F_pil.affine`; the affine matrix there is taken about the image centre).  Interior pixels agree to 1e-5: geometry,
+    direction of rotation, centre convention, half-pixel offsets and the interpolation are pinned; the border band differs by construction (PIL
+    fills, the tensor path blends with a sampled ones-mask) and stays covered by the ones-mask invariants only."""
+    Image = pytest.importorskip('PIL.Image')
+    from oracle import augment_ref as A
+    g = torch.Generator().manual_seed(0)
+    h, w = 64, 80
+    x = torch.rand(1, 1, h, w, generator=g)
+    img = Image.fromarray(x[0, 0].numpy().astype(np.float32), mode='F')
+    inner = (slice(12, -12), slice(12, -12))
+    start = [[0, 0], [w - 1, 0], [w - 1, h - 1], [0, h - 1]]
+    for end in ([[5, 7], [70, 2], [75, 60], [3, 55]], [[0, 0], [w - 1, 0], [w - 1, h - 1], [0, h - 1]], [[9, 1], [78, 8], [70, 62], [1, 50]]):
+        co = A.perspective_coeffs(start, end)
+        ref = A.perspective(x, co)[0, 0].numpy()
+        pil = np.asarray(img.transform(img.size, Image.PERSPECTIVE, co, Image.BILINEAR))
+        assert np.abs(ref - pil)[inner].max() < 3e-5, end
+    for (ang, t, sc, sh) in ((30.0, [0, 0], 1.0, 0.0), (-17.0, [0, 0], 1.0, 0.0), (0.8, [0.0, 10.0], 1.012, 0.4), (-2.5, [7.0, -3.0], 0.97, -1.2)):
+        a, b, c0, d, e, f0 = A.inverse_affine_matrix(ang, t, sc, sh)            # about the centre; PIL wants it in pixel coordinates
+        cx, cy = w * 0.5, h * 0.5
+        mat = [a, b, c0 + cx - a * cx - b * cy, d, e, f0 + cy - d * cx - e * cy]
+        pil = np.asarray(img.transform(img.size, Image.AFFINE, mat, Image.BILINEAR))
+        assert np.abs(A.affine(x, ang, t, sc, sh)[0, 0].numpy() - pil)[inner].max() < 3e-5, (ang, t, sc, sh)
+        if t == [0, 0] and sc == 1.0 and sh == 0.0:
+            assert np.abs(A.rotate(x, ang)[0, 0].numpy() - pil)[inner].max() < 3e-5, ang        # random_rotate_fast: the same map
+
+
 def test_torchvision_fixture():
     """a-8 / f-1: the restated torchvision maths against torchvision's own outputs (tests/golden/tf_fast_224.npz, when someone with
     torchvision has generated it: oracle/make_tv_fixture.py); skipped with the reason otherwise"""
