@@ -223,6 +223,54 @@ def check_kernels_vs_tv_fixture(lib, dev, fx):
         assert (got - torch.from_numpy(fx['affine_out'][i:i + 1])).abs().max().item() < 2e-4, i
 
 
+def check_kernels_vs_pil(lib, dev, size=64, patch=32):
+    """the HIP sampler's perspective / rotation stages and aph_frame_affine against Pillow's float `Image.transform` (the implementation behind
+    torchvision's PIL backend; interior pixels -- the border band blends differently by construction).  Every cut is a size x size image with an
+    identity crop, so only the warp is compared."""
+    from PIL import Image
+    from aphantasia_amd import transforms as T
+    g = torch.Generator().manual_seed(3)
+    cut = torch.rand(3, size, size, generator=g)
+    geom = ops.make_geom(size, size, 1, size, patch=patch)
+    table = torch.tensor([[size, 0, 0]], dtype=torch.int32, device=dev)
+    def covered(warp_ones):
+        """pixels whose whole bilinear footprint lies inside the source (warped all-ones image == 1), eroded by one pixel: where the
+        two implementations must agree; elsewhere Pillow fills and the tensor path blends"""
+        m = (warp_ones[0, 0] > 1 - 1e-6).float()[None, None]
+        m = -torch.nn.functional.max_pool2d(-m, 3, 1, 1)
+        return m[0, 0].bool().numpy()
+    ones = torch.ones(1, 1, size, size)
+    start = [[0, 0], [size - 1, 0], [size - 1, size - 1], [0, size - 1]]
+    ends = ([[4, 6], [57, 2], [60, 58], [3, 52]], [[7, 1], [62, 5], [55, 61], [1, 50]])
+    pil_of = lambda ch, mode, coef: np.asarray(Image.fromarray(cut[ch].numpy().astype(np.float32), mode='F').transform((size, size), mode, coef, Image.BILINEAR))
+    for end in ends:
+        co = augment_ref.perspective_coeffs(start, end)
+        out = ops.sample_fwd(geom, cut.to(dev).contiguous(), table, aug=pack_aug([dict(persp=co, erase=None, angle=None)]).to(dev), out_mode=_ffi.APH_OUT_NCHW_RAW,
+                             lib=lib).cpu()[0]
+        want = np.stack([pil_of(ch, Image.PERSPECTIVE, co) for ch in range(3)])
+        ok = covered(augment_ref.perspective(ones, co))
+        assert ok.mean() > 0.5 and np.abs(out.numpy() - want)[:, ok].max() < 2e-4, end
+    for ang in (30.0, -17.0, 5.0):
+        out = ops.sample_fwd(geom, cut.to(dev).contiguous(), table, aug=pack_aug([dict(persp=None, erase=None, angle=ang)]).to(dev), out_mode=_ffi.APH_OUT_NCHW_RAW,
+                             lib=lib).cpu()[0]
+        a, b, c0, d, e, f0 = augment_ref.inverse_affine_matrix(ang, [0, 0], 1.0, 0.0)
+        cx = cy = size * 0.5
+        mat = [a, b, c0 + cx - a * cx - b * cy, d, e, f0 + cy - d * cx - e * cy]
+        want = np.stack([pil_of(ch, Image.AFFINE, mat) for ch in range(3)])
+        ok = covered(augment_ref.rotate(ones, ang))
+        assert ok.mean() > 0.5 and np.abs(out.numpy() - want)[:, ok].max() < 2e-4, ang
+    h, w = 48, 72
+    frame = torch.rand(1, 3, h, w, generator=g)
+    for (ang, t, sc, sh) in ((0.8, [0.0, 10.0], 1.012, 0.4), (-2.5, [7.0, -3.0], 0.97, -1.2)):
+        got = T.frame_transform(frame.to(dev), (h, w), ang, t, sc, sh, lib=lib).cpu()[0]
+        a, b, c0, d, e, f0 = augment_ref.inverse_affine_matrix(ang, t, sc, sh)
+        cx, cy = w * 0.5, h * 0.5
+        mat = [a, b, c0 + cx - a * cx - b * cy, d, e, f0 + cy - d * cx - e * cy]
+        want = np.stack([np.asarray(Image.fromarray(frame[0, ch].numpy().astype(np.float32), mode='F').transform((w, h), Image.AFFINE, mat, Image.BILINEAR)) for ch in range(3)])
+        ok = covered(augment_ref.affine(torch.ones(1, 1, h, w), ang, t, sc, sh))
+        assert ok.mean() > 0.5 and np.abs(got.numpy() - want)[:, ok].max() < 2e-4, (ang, t, sc, sh)
+
+
 def check_augment_invariants(lib, dev, size=32, patch=16):
     """Properties the real torchvision ops satisfy (transforms.py:165-170), checked on the HIP sampler: a-8 stays
     "parity unpinned" (no torchvision in the image) -- these pin what can be pinned without it."""

@@ -62,6 +62,11 @@ def test_sampler_augment(emu):
     K.check_sampler_augment(emu, 'cpu', H=80, W=96, S=6, size=64, patch=16)      # full 32x32 tiles: LDS-staged patch-major emit
 
 
+def test_augment_kernels_vs_pillow(emu):
+    pytest.importorskip('PIL.Image')
+    K.check_kernels_vs_pil(emu, 'cpu')
+
+
 def test_augment_invariants(emu):
     K.check_augment_invariants(emu, 'cpu')
 

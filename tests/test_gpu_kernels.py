@@ -142,6 +142,12 @@ def test_sampler_random_geometries(monkeypatch):
         K.check_sampler_adjoint(None, DEV, 'overscan', 0, H=H, W=72, S=4, size=8, patch=8)
 
 
+def test_augment_kernels_vs_pillow():
+    """perspective / rotation stages of the sampler and aph_frame_affine against Pillow's float Image.transform (interior pixels)"""
+    pytest.importorskip('PIL.Image')
+    K.check_kernels_vs_pil(None, DEV)
+
+
 def test_augment_vs_torchvision_fixture():
     """the sampler's perspective / erase / rotate stages and aph_frame_affine against torchvision's outputs (skips while the fixture is absent)"""
     K.check_kernels_vs_tv_fixture(None, DEV, K.tv_fixture_or_skip())

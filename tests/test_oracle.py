@@ -183,21 +183,26 @@ def test_augment_geometry_vs_pil_float_transforms():
     h, w = 64, 80
     x = torch.rand(1, 1, h, w, generator=g)
     img = Image.fromarray(x[0, 0].numpy().astype(np.float32), mode='F')
-    inner = (slice(12, -12), slice(12, -12))
+    def covered(warp_ones):        # whole bilinear footprint inside the source, eroded by one pixel (elsewhere Pillow fills, the tensor path blends)
+        m = -torch.nn.functional.max_pool2d(-(warp_ones > 1 - 1e-6).float(), 3, 1, 1)
+        return m[0, 0].bool().numpy()
+    ones = torch.ones(1, 1, h, w)
     start = [[0, 0], [w - 1, 0], [w - 1, h - 1], [0, h - 1]]
     for end in ([[5, 7], [70, 2], [75, 60], [3, 55]], [[0, 0], [w - 1, 0], [w - 1, h - 1], [0, h - 1]], [[9, 1], [78, 8], [70, 62], [1, 50]]):
         co = A.perspective_coeffs(start, end)
         ref = A.perspective(x, co)[0, 0].numpy()
         pil = np.asarray(img.transform(img.size, Image.PERSPECTIVE, co, Image.BILINEAR))
-        assert np.abs(ref - pil)[inner].max() < 3e-5, end
+        ok = covered(A.perspective(ones, co))
+        assert ok.mean() > 0.5 and np.abs(ref - pil)[ok].max() < 3e-5, end
     for (ang, t, sc, sh) in ((30.0, [0, 0], 1.0, 0.0), (-17.0, [0, 0], 1.0, 0.0), (0.8, [0.0, 10.0], 1.012, 0.4), (-2.5, [7.0, -3.0], 0.97, -1.2)):
         a, b, c0, d, e, f0 = A.inverse_affine_matrix(ang, t, sc, sh)            # about the centre; PIL wants it in pixel coordinates
         cx, cy = w * 0.5, h * 0.5
         mat = [a, b, c0 + cx - a * cx - b * cy, d, e, f0 + cy - d * cx - e * cy]
         pil = np.asarray(img.transform(img.size, Image.AFFINE, mat, Image.BILINEAR))
-        assert np.abs(A.affine(x, ang, t, sc, sh)[0, 0].numpy() - pil)[inner].max() < 3e-5, (ang, t, sc, sh)
+        ok = covered(A.affine(ones, ang, t, sc, sh))
+        assert ok.mean() > 0.5 and np.abs(A.affine(x, ang, t, sc, sh)[0, 0].numpy() - pil)[ok].max() < 3e-5, (ang, t, sc, sh)
         if t == [0, 0] and sc == 1.0 and sh == 0.0:
-            assert np.abs(A.rotate(x, ang)[0, 0].numpy() - pil)[inner].max() < 3e-5, ang        # random_rotate_fast: the same map
+            assert np.abs(A.rotate(x, ang)[0, 0].numpy() - pil)[ok].max() < 3e-5, ang        # random_rotate_fast: the same map
 
 
 def test_torchvision_fixture():
