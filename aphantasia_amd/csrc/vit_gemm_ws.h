@@ -48,7 +48,11 @@ using GemmWS = GemmWSCfg<256, 2, 3, 1, 4096>;
 // workgroup only leaves a 2-stage ring, which exposes the DMA latency on every k-tile: a lone 128 x 128 workgroup needs 0.77 us per k-tile
 // where the 256 x 128 one needs 0.84 for twice the work, and two of them per CU do not make up for it (QKV 55-68 us against 47-49; fc2, one
 // tile per workgroup and every workgroup resident: 65 us against 42).  About a third of the second workgroups also started only when a first
-// one had left (entry / exit stamps on the chip-wide clock), although the occupancy API reports 2 per CU.)
+// one had left (entry / exit stamps on the chip-wide clock), although the occupancy API reports 2 per CU: a 5-wave workgroup puts two waves on
+// one SIMD, and when both workgroups' pairs land on the same SIMD, 4 waves x 144 VGPRs do not fit.  Second look: with one fragment buffer the
+// kernel fits 128 VGPRs (four waves per SIMD) and every one of the 512 workgroups enters within 0.8 us -- and the pair is then EQUAL to the
+// single 256 x 128 workgroup, not better (QKV f16 41.0 vs 38.9 us, fc1 + GELU 64.9 vs 63.3, fc2 52.9 vs 49.7): what the out-of-phase partner
+// hides is given back by the 2-stage ring, the exposed fragment reads and the smaller tile.)
 
 // LDS row v of the Bt tile (0..127) holds tile row perm(v): within each 64-row block (one consumer column group), fragment row
 // i = v & 15 of column tile nt = (v >> 4) & 3 is weight row 4 i + nt.  The MFMAs take the TOKENS as their A fragment and the weights
