@@ -88,7 +88,7 @@ class Engine:
         # static loss scale of the fp16 backward with back-off: an overflowed step (NaN / inf gradient) is skipped on the
         # device (aph_adam_step_guarded); the host looks at the skip counter every GUARD_EVERY steps and halves the scale
         self.loss_scale = float(LOSS_SCALE if loss_scale is None else loss_scale)
-        self._guard_seen, self._guard_host, self._guard_ev = 0, None, None
+        self._guard_seen, self._guard_host, self._guard_ev, self._guard_rebase = 0, None, None, False
         self.enforce = float(enforce)                               # clip_fft.py:271-275
         # aest = (weight [D] or [1,D], bias, strength): `loss -= 0.001 * strength * (enc @ w + b).mean()` (clip_fft.py:255-256,
         # utils.py:402-413: the LAION linear aesthetic predictor on the raw encodings)
@@ -374,7 +374,7 @@ class Engine:
         if count > self._guard_seen:
             # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either (not carried across a
             # reset_params: those skips belonged to the previous frame's optimiser)
-            if not getattr(self, '_guard_rebase', False):
+            if not self._guard_rebase:
                 self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
             self._guard_seen = count
             self._guard_rebase = False
