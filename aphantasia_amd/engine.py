@@ -140,18 +140,31 @@ class Engine:
         self.loss = torch.zeros(1, **f32)
         self.prior_ws = torch.empty(int(self.lib.cdll.aph_rgb_priors_ws_bytes()) // 8, device=self.dev, dtype=torch.float64)
         self.ws = torch.empty(Sl * (len(self.coef) + 2), **f32)
-        self.hyper = torch.empty(8, **f32)
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.dev)      # [skipped-step count, scratch]
         self._own_stream = None
         self._stage, self._stage_i = None, 0       # pinned host ring for the per-step H2D refreshes (built lazily, GPU only)
         self.geom = ops.make_geom(h, w, Sl, self.size, self.patch, align)
-        self.table = torch.empty(Sl, 3, dtype=torch.int32, device=self.dev)
         self.geometric = isinstance(transform, Transform) and transform.geometric
-        self.aug = torch.empty(Sl, _ffi.APH_AUG_STRIDE, **f32) if self.geometric else None
+        # Per-step host inputs (Adam scalars | crop table | augment table [| second set for --enforce]) live in ONE device
+        # buffer, refreshed by one H2D copy per step; the named tensors are views of it (16-byte aligned).
+        parts = [('hyper', (8,), torch.float32), ('table', (Sl, 3), torch.int32)]
+        if self.geometric:
+            parts.append(('aug', (Sl, _ffi.APH_AUG_STRIDE), torch.float32))
+        if self.enforce != 0:
+            parts.append(('table2', (Sl, 3), torch.int32))
+            if self.geometric:
+                parts.append(('aug2', (Sl, _ffi.APH_AUG_STRIDE), torch.float32))
+        self.aug = self.aug2 = self.table2 = None
+        self._stepin_layout, words = [], 0
+        for name, shape, dt in parts:
+            n = int(np.prod(shape))
+            self._stepin_layout.append((name, words, n, shape, dt))
+            words += (n + 3) // 4 * 4
+        self._stepin = torch.zeros(words, dtype=torch.int32, device=self.dev)
+        for name, v in self._stepin_views(self._stepin).items():
+            setattr(self, name, v)
         self.tmp = ops.sample_ws(self.geom, self.geometric, self.dev, self.lib)      # engine-owned: tap tables + augmentation scratch
         if self.enforce != 0:          # second, independently drawn set of cuts of the same image
-            self.table2 = torch.empty_like(self.table)
-            self.aug2 = torch.empty_like(self.aug) if self.geometric else None
             self.enc2, self.genc2, self.grgb2 = torch.empty_like(self.enc), torch.empty_like(self.genc), torch.empty_like(self.grgb)
             self.loss2 = torch.zeros(1, **f32)
             self.ws2 = torch.empty(Sl * 3, **f32)
@@ -316,6 +329,9 @@ class Engine:
                ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
         self.visual._forward_patches(self.patches, Sl, self.enc)
 
+    def _stepin_views(self, flat):
+        return {name: flat[o:o + n].view(dt).view(shape) for name, o, n, shape, dt in self._stepin_layout}
+
     def _upload(self, hy, table, augs, table2, augs2):
         """Refresh the device-side per-step inputs (Adam scalars, crop table, augment table).  On the GPU the values go
         through a ring of PINNED host buffers owned by the engine: the async copies never read from a temporary, and the
@@ -323,28 +339,31 @@ class Engine:
         Sl = self.S_loc
         rows = lambda a: torch.from_numpy(np.ascontiguousarray(a[self.lo:self.hi]))
         packed = lambda a: rows(a) if isinstance(a, np.ndarray) else pack_aug(a[self.lo:self.hi])
-        items = [(self.hyper, torch.tensor(hy, dtype=torch.float32))]
+        items = [('hyper', torch.tensor(hy, dtype=torch.float32))]
         if Sl > 0:
-            items.append((self.table, rows(table)))
+            items.append(('table', rows(table)))
             if self.geometric:
-                items.append((self.aug, packed(augs)))
+                items.append(('aug', packed(augs)))
             if self.enforce != 0:
-                items.append((self.table2, rows(table2)))
+                items.append(('table2', rows(table2)))
                 if self.geometric:
-                    items.append((self.aug2, packed(augs2)))
+                    items.append(('aug2', packed(augs2)))
         if not self.params.is_cuda:
-            for dst, src in items:
-                dst.copy_(src)
+            for name, src in items:
+                getattr(self, name).copy_(src)
             return
         if self._stage is None:
-            self._stage = [dict(bufs=[torch.empty(d.shape, dtype=d.dtype).pin_memory() for d, _ in items], ev=None) for _ in range(4)]
+            self._stage = []
+            for _ in range(4):
+                flat = torch.zeros(self._stepin.shape, dtype=torch.int32).pin_memory()
+                self._stage.append(dict(flat=flat, views=self._stepin_views(flat), ev=None))
         slot = self._stage[self._stage_i % len(self._stage)]
         self._stage_i += 1
         if slot['ev'] is not None:
-            slot['ev'].synchronize()            # the copies issued from this slot four steps ago have been consumed
-        for (dst, src), buf in zip(items, slot['bufs']):
-            buf.copy_(src)
-            dst.copy_(buf, non_blocking=True)
+            slot['ev'].synchronize()            # the copy issued from this slot four steps ago has been consumed
+        for name, src in items:
+            slot['views'][name].copy_(src.reshape(slot['views'][name].shape))
+        self._stepin.copy_(slot['flat'], non_blocking=True)
         slot['ev'] = torch.cuda.Event()
         slot['ev'].record()
 
