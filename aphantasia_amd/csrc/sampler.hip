@@ -41,6 +41,15 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
 // four consecutive floats at 4-byte alignment: the compiler emits one global_load_dwordx4 (gfx950 handles the misalignment)
 struct __attribute__((packed, aligned(4))) F4u { float v[4]; };
 
+// "every ACTIVE lane of the wave satisfies p" (a speed choice only: the test interpreter decides per lane)
+__device__ __forceinline__ bool wave_all(bool p) {
+#ifdef APH_EMU
+  return p;
+#else
+  return __builtin_amdgcn_ballot_w64(!p) == 0;
+#endif
+}
+
 // v mod n for the wrap-tiled overscan frame (utils.py:165-167).  The padded frame is at most 2x the image (overmax), so
 // v lies in [-n, 2n): one conditional correction instead of an integer division (there are eight of these per output
 // pixel of the bicubic resize -- with `%` they were most of that kernel's instructions); the generic path is kept for safety.
@@ -152,8 +161,25 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
     rx[k] = wrap(b.ox + xx - g.px0, g.W);
   }
   // the four column taps are consecutive source pixels unless the clamp at the cut's edge or the wrap at the image's
-  // edge intervenes: one 16-byte load per tap row (4-byte aligned) instead of four scalar gathers
-  const bool run4 = rx[3] == rx[0] + 3;
+  // edge intervenes: one 16-byte load per tap row (4-byte aligned) instead of four scalar gathers.  [r3] The choice is made per
+  // WAVE: with a per-lane branch the compiler shared the first and last tap between the two paths and emitted dword + dwordx2 + dword
+  // per tap row, each behind its own divergent branch (46 vector-memory instructions per wave and pixel; the kernel is bound by the
+  // L1's access rate: TCP_TOTAL_CACHE_ACCESSES 150 M per launch at C2).
+  if (wave_all(rx[3] == rx[0] + 3)) {
+    F4u t[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) t[c][a] = *reinterpret_cast<const F4u*>(rgb + ((size_t)c * g.H + ry[a]) * g.W + rx[0]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc += (t[c][a].v[0] * wx[0] + t[c][a].v[1] * wx[1] + t[c][a].v[2] * wx[2] + t[c][a].v[3] * wx[3]) * wy[a];
+      v[c] = acc;
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* pl = rgb + (size_t)c * g.H * g.W;
@@ -161,14 +187,7 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const float* row = pl + (size_t)ry[a] * g.W;
-      float r;
-      if (run4) {
-        const F4u t = *reinterpret_cast<const F4u*>(row + rx[0]);
-        r = t.v[0] * wx[0] + t.v[1] * wx[1] + t.v[2] * wx[2] + t.v[3] * wx[3];
-      } else {
-        r = row[rx[0]] * wx[0] + row[rx[1]] * wx[1] + row[rx[2]] * wx[2] + row[rx[3]] * wx[3];
-      }
-      acc += r * wy[a];
+      acc += (row[rx[0]] * wx[0] + row[rx[1]] * wx[1] + row[rx[2]] * wx[2] + row[rx[3]] * wx[3]) * wy[a];
     }
     v[c] = acc;
   }
@@ -176,26 +195,27 @@ __device__ __forceinline__ void bicubic3(const float* __restrict__ rgb, const Ge
 
 // XCD-aware forward (speed only; any assignment is correct).  The image (11 MB at 720p) does not fit one XCD's 4 MB L2, and with
 // the plain (x, y, cut) grid every XCD gathers from all of it: 487 MB of fabric fetch per launch for 11 MB of source.  Here the
-// unit of work is (cut, group of 4 output rows); strip_list_kernel assigns every unit to the XCD that owns the 32-pixel image
+// unit of work is (cut, group of 4 output rows); strip_list_kernel assigns every unit to the XCD that owns the 16-pixel image
 // strip its source rows fall into (strips interleaved over the XCDs: strip t -> XCD t % 8, so every XCD sees centre and edge
 // strips alike), and crop_resize_strips_kernel's workgroup b, which runs on XCD b % 8 (observed dispatch order), walks that
 // XCD's list.  An XCD then touches ~1.4 / 8 of the image.
-constexpr int kStripPx = 32;
+constexpr int kStripPx = 16;          // [r3] 32 -> 16: the 22.5 strips of a 720-row image left one XCD a third short of work (148 -> 145 us; 8: 143.5, 64: 170)
+constexpr int kUnitRows = 4;              // output rows of one unit of work (8: 153 us against 145; 128-thread workgroups: 150)
 constexpr int kStripSlots = 768;          // workgroups per XCD in crop_resize_strips_kernel
 
 // lists: [8][cap] unit ids (cut * groups + row group), counts: [8]; one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void strip_list_kernel(const int* __restrict__ table, int* __restrict__ lists, int* __restrict__ counts, int cap, Geom g) {
+__global__ __launch_bounds__(1024) void strip_list_kernel(const int* __restrict__ table, int* __restrict__ lists, int* __restrict__ counts, int cap, Geom g, int strip_px) {
   __shared__ int cnt[8];
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int groups = (g.size + 3) / 4, units = g.S * groups;
+  const int groups = (g.size + kUnitRows - 1) / kUnitRows, units = g.S * groups;
   for (int u = threadIdx.x; u < units; u += blockDim.x) {
     const int s = u / groups, rg = u - s * groups;
     const CutBox b = load_cut(table, s, g.size);
-    int i = rg * 4 + 2; i = i > g.size - 1 ? g.size - 1 : i;
+    int i = rg * kUnitRows + kUnitRows / 2; i = i > g.size - 1 ? g.size - 1 : i;
     int yy = (int)floorf(b.scale * (float)i); yy = yy > b.cs - 1 ? b.cs - 1 : yy;
     const int yc = wrap(b.oy + yy - g.py0, g.H);
-    const int xcd = (yc / kStripPx) & 7;
+    const int xcd = (yc / strip_px) & 7;
     const int pos = atomicAdd(&cnt[xcd], 1);            // (order inside a list is irrelevant: units are independent)
     lists[xcd * cap + pos] = u;
   }
@@ -207,13 +227,13 @@ template <int OUT>
 __global__ __launch_bounds__(256) void crop_resize_strips_kernel(const float* __restrict__ rgb, const int* __restrict__ table, void* __restrict__ out, Geom g,
                                                                  const int* __restrict__ lists, const int* __restrict__ counts, int cap) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-  const int count = counts[xcd], groups = (g.size + 3) / 4, n = g.size;
+  const int count = counts[xcd], groups = (g.size + kUnitRows - 1) / kUnitRows, n = g.size;
   for (int it = slot; it < count; it += nslot) {
     const int u = lists[xcd * cap + it];
     const int s = u / groups, rg = u - s * groups;
     const CutBox b = load_cut(table, s, n);
-    for (int p = threadIdx.x; p < 4 * n; p += blockDim.x) {
-      const int di = p / n, j = p - di * n, i = rg * 4 + di;
+    for (int p = threadIdx.x; p < kUnitRows * n; p += blockDim.x) {
+      const int di = p / n, j = p - di * n, i = rg * kUnitRows + di;
       if (i >= n) continue;
       float v[3];
       bicubic3(rgb, g, b, i, j, v);
@@ -449,13 +469,29 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
 // The gather kernel above visits every (pixel, covering cut) pair with up to 16 gathers x 3 channels and is bound by that per-pair
 // skeleton (332 us at C2).  Here a workgroup owns RB image rows of ONE channel across the whole width, every thread owns CPT columns and
 // keeps their RB accumulators in registers.  The covering cuts are walked in index order (deterministic, no atomics) in batches of NBC:
-//   phase 0  the batch's cut boxes and their RB row-tap entries -> LDS
-//   phase 1  column pass: U[b][j][q] = sum_a wy[a] * G_b[i_a][j] for the RB rows and all `size` columns of each cut (coalesced along j;
-//            a gradient row is read by the 1-2 row blocks its taps land in, not once per pixel)
+//   phase 0  the batch's cut boxes -> LDS; per (cut, four image rows) the union of the <= 8 gradient rows their taps come from, with
+//            one weight per image row (QuadRow)
+//   phase 1  column pass: U[b][j][4 qq .. 4 qq + 3] = sum_r W[r][.] * G_b[i_lo + r][j] for all `size` columns of each cut (coalesced
+//            along j; a gradient row is read once per four image rows it feeds, the four results leave as one 16-byte LDS write)
 //   phase 2  row pass: acc[q][x] += sum_b wx[b] * U[b][j_b][q], the RB rows of a column tap fetched as 16-byte LDS reads
 // Up-sampling cuts (cs < size: never at 1280x720) take the per-pixel generic path of the gather kernel.
 // ---------------------------------------------------------------------------------
-constexpr int ADJ_NBC = 8;          // cuts per batch (the launcher lowers it when LDS is short)
+struct __attribute__((aligned(16))) QuadRow {      // one gradient row of the union behind four consecutive image rows of a cut
+  float w[4];        // its weight on each of the four image rows
+  int off;           // gradient-layout row offset, -1 = unused
+  int pad[3];
+};
+// inverse of grad_rowpart
+template <int OUT>
+__device__ __forceinline__ int grad_row_of_off(int off, int size, int p) {
+  if (is_patch<OUT>::v) {
+    const int lp = __ffs(p) - 1, rs = (size >> lp) * (3 << (2 * lp));
+    const int ip = off / rs;
+    return (ip << lp) + ((off - ip * rs) >> lp);
+  }
+  return off / size;
+}
+constexpr int ADJ_NBC = 12;         // cuts per batch (the launcher lowers it when LDS is short)
 template <int OUT>
 __device__ __forceinline__ int grad_col_of_off(int off, int p) {         // inverse of grad_colpart
   if (is_patch<OUT>::v) {
@@ -470,13 +506,14 @@ template <int OUT, int RBQ, int CPT>
 __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __restrict__ gout, float gscale, const int* __restrict__ table,
                                                                  float* __restrict__ grgb, Geom g, const AdjEntry* __restrict__ tab, int maxcs,
                                                                  int RB, int NBC, int dbg) {
-  constexpr int RBP = RBQ * 4, MAXV = 1024;
+  constexpr int RBP = RBQ * 4, MAXV = 512;
   APH_DYN_SMEM(smem);
   float* U = reinterpret_cast<float*>(smem);                                   // [NBC][size][RBP]
-  AdjEntry* ent = reinterpret_cast<AdjEntry*>(U + (size_t)NBC * g.size * RBP); // [NBC][RBP]
-  int* binfo = reinterpret_cast<int*>(ent + NBC * RBP);                        // [NBC][4] = s (-1: none), cs, ox, oy (cs < 0: generic cut)
-  int* vlist = binfo + NBC * 4;                                                // [MAXV]
-  int* vcount = vlist + MAXV;
+  QuadRow* qtab2 = reinterpret_cast<QuadRow*>(U + (size_t)NBC * g.size * RBP); // [2][NBC][RBQ][8]: the <= 8 gradient rows behind four image rows
+  int* binfo2 = reinterpret_cast<int*>(qtab2 + 2 * NBC * RBQ * 8);             // [2][NBC][4] = s (-1: none), cs, ox, oy (cs < 0: generic cut)
+  int* vlist = binfo2 + 2 * NBC * 4;                                           // [MAXV]
+  int* vbox = vlist + MAXV;                                                    // [MAXV][3] = cs, ox, oy of the listed cuts
+  int* vcount = vbox + 3 * MAXV;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.y, y0 = blockIdx.x * RB;
   const int rows = g.H - y0 < RB ? g.H - y0 : RB;
@@ -497,118 +534,175 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
       for (int v0 = 0; v0 < vend; v0 += 64) {
         const int s = vbase + v0 + tid;
         bool hit = false;
+        int cs = 0, ox = 0, oy = 0;
         if (v0 + tid < vend) {
-          const int cs = table[3 * s], oy = table[3 * s + 2];
+          cs = table[3 * s]; ox = table[3 * s + 1]; oy = table[3 * s + 2];
           hit = oy < y0 + rows && oy + cs > y0;
         }
         const unsigned long long m = __ballot(hit);
-        if (hit) vlist[count + __popcll(m & ((1ull << tid) - 1ull))] = s;
+        if (hit) {
+          const int pos = count + __popcll(m & ((1ull << tid) - 1ull));
+          vlist[pos] = s; vbox[3 * pos] = cs; vbox[3 * pos + 1] = ox; vbox[3 * pos + 2] = oy;
+        }
         count += __popcll(m);
       }
       if (tid == 0) *vcount = count;
     }
     __syncthreads();
     const int nlist = *vcount;
-    for (int b0 = 0; b0 < nlist; b0 += NBC) {
-      // ---- phase 0: boxes and row entries of the batch
-      if (tid < NBC * RBP) {
-        const int b = tid / RBP, q = tid - b * RBP;
-        AdjEntry e;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { e.off[a] = 0; e.w[a] = 0.f; }
+    // ---- phase 0 (of batch b0, into table buffer `buf`): boxes of the batch, and per (cut, four image rows) the union of the gradient
+    // rows their taps come from.  Image row y of a down-sampling cut (scale >= 1) is touched by output rows i with floor(i scale) in
+    // [y - 2, y + 1] (clamped taps land on rows that are in that set anyway), so four consecutive image rows draw on i in
+    // [(y - 2) / scale, (y + 5) / scale): at most 8 rows.  Thread (b, qq, r) merges the four per-row tap entries into row r of that
+    // union: gradient offset + 4 weights.
+    // It runs one batch AHEAD, on the last 256 threads during the row pass of the batch before: those threads own the fewest columns
+    // (W = 1280 on 768 threads x 2 columns: the last four waves have one), so the two dependent table loads cost the batch nothing.
+    constexpr int P0_THREADS = 256;
+    const int p0_first = nthr - P0_THREADS;
+    auto phase0 = [&](int b0, int buf) {
+      if (tid < p0_first) return;
+      QuadRow* qt = qtab2 + buf * NBC * RBQ * 8;
+      int* bi = binfo2 + buf * NBC * 4;
+      for (int pt = tid - p0_first; pt < NBC * RBQ * 8; pt += P0_THREADS) {
+        const int b = pt / (RBQ * 8), qq = (pt >> 3) % RBQ, r = pt & 7;
+        QuadRow qr;
+        qr.off = -1; qr.w[0] = qr.w[1] = qr.w[2] = qr.w[3] = 0.f;
         if (b0 + b < nlist) {
           const int s = vlist[b0 + b];
-          const int cs = table[3 * s], ox = table[3 * s + 1], oy = table[3 * s + 2];
+          const int cs = vbox[3 * (b0 + b)], ox = vbox[3 * (b0 + b) + 1], oy = vbox[3 * (b0 + b) + 2];      // (kept by the list build: one dependent load less)
           const float scale = g.size > 1 ? (float)(cs - 1) / (float)(g.size - 1) : 0.f;
           const bool generic = !(scale >= 1.0f);
-          if (q == 0) { binfo[4 * b] = s; binfo[4 * b + 1] = generic ? -cs : cs; binfo[4 * b + 2] = ox; binfo[4 * b + 3] = oy; }
-          const int yc = y0 + q - oy;
-          if (!generic && q < rows && yc >= 0 && yc < cs && yc < maxcs) e = tab[((size_t)s * 2) * maxcs + yc];
-        } else if (q == 0) binfo[4 * b] = -1;
-        ent[tid] = e;
+          if (qq == 0 && r == 0) { bi[4 * b] = s; bi[4 * b + 1] = generic ? -cs : cs; bi[4 * b + 2] = ox; bi[4 * b + 3] = oy; }
+          if (!generic) {
+            AdjEntry e[4];
+            int i0[4], ilo = 1 << 30;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int q = 4 * qq + k, yc = y0 + q - oy;
+              const bool live = q < rows && yc >= 0 && yc < cs && yc < maxcs;
+              if (live) e[k] = tab[((size_t)s * 2) * maxcs + yc];
+              i0[k] = 1 << 30;
+              if (live && (e[k].w[0] != 0.f || e[k].w[1] != 0.f || e[k].w[2] != 0.f || e[k].w[3] != 0.f)) i0[k] = grad_row_of_off<OUT>(e[k].off[0], g.size, g.patch);
+              else { e[k].w[0] = e[k].w[1] = e[k].w[2] = e[k].w[3] = 0.f; }
+              ilo = i0[k] < ilo ? i0[k] : ilo;
+            }
+            if (ilo < (1 << 30)) {
+              const int i = ilo + r;
+              bool any = false;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                float w = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) w += (i0[k] + a == i) ? e[k].w[a] : 0.f;
+                qr.w[k] = w;
+                any = any || w != 0.f;
+              }
+              if (any && i < g.size) qr.off = grad_rowpart<OUT>(i, g.size, g.patch);
+            }
+          }
+        } else if (qq == 0 && r == 0) bi[4 * b] = -1;
+        qt[pt] = qr;
       }
-      __syncthreads();
-      // ---- phase 1: column pass into U[b][j][q]: one wave per (cut, row) pair, lanes across the cut's columns
+    };
+    phase0(0, 0);
+    __syncthreads();
+    for (int b0 = 0, cur = 0; b0 < nlist; b0 += NBC, cur ^= 1) {
+      const QuadRow* qtab = qtab2 + cur * NBC * RBQ * 8;
+      const int* binfo = binfo2 + cur * NBC * 4;
+      // ---- phase 1: column pass into U[b][j][4 qq .. 4 qq + 3]: one wave per (cut, four rows), lanes across the cut's columns; the
+      // gradient rows of the union are read once for the four image rows they feed, and the four results leave as one 16-byte LDS write
+      // (the scalar writes of a per-row pass are 8-way bank conflicted under the 16-byte-aligned column pitch the row pass needs)
       const int nb = nlist - b0 < NBC ? nlist - b0 : NBC;
       if (!(dbg & 1)) {
-        // two (cut, row) pairs per wave and trip, every gather of both issued before the first is used: the pass is bound by memory
-        // latency (a lone wave waiting for 4 loads per trip measured 340 us of a 540 us kernel)
-        const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6, npair = nb * RB;
+        // one quad per wave and trip, its 32 gathers issued before the first is used: the pass is bound by memory latency
+        const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6, nquad = nb * RBQ;
         constexpr int JT = 4;                                      // column trips of 64 lanes: size <= 256 (checked by the launcher)
-        for (int pq0 = wv; pq0 < npair; pq0 += 2 * nwv) {
-          float u[2][JT];
-          AdjEntry e[2];
-          size_t gb[2];
-          int bq[2][2];
+        unsigned colj[JT];                                         // 32-bit lane offsets against a scalar row base: one address register per column trip
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int pq = pq0 + h * nwv;
-            const bool ok = pq < npair;
-            const int b = ok ? pq / RB : 0, q = ok ? pq - b * RB : 0;
-            bq[h][0] = ok ? b : -1; bq[h][1] = q;
-            e[h] = ent[b * RBP + q];
-            if (!ok) { e[h].w[0] = 0.f; e[h].w[1] = 0.f; e[h].w[2] = 0.f; e[h].w[3] = 0.f; }
-            gb[h] = (size_t)binfo[4 * b] * ccut + (size_t)c * cchan;
+        for (int m = 0; m < JT; ++m) { const int j = lane + 64 * m; colj[m] = (unsigned)grad_colpart<OUT>(j < g.size ? j : 0, g.size, g.patch); }
+        for (int pq = wv; pq < nquad; pq += nwv) {
+          float v[JT][8];
+          const int b = pq / RBQ, qq = pq - b * RBQ;
+          const size_t gb = (size_t)wave_uniform(binfo[4 * b]) * ccut + (size_t)c * cchan;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int off = wave_uniform(qtab[pq * 8 + r].off);
+            const size_t rowbase = gb + (size_t)(off >= 0 ? off : 0);
+#pragma unroll
+            for (int m = 0; m < JT; ++m) {
+              float x = 0.f;
+              if (off >= 0 && lane + 64 * m < g.size) {
+                if (OUT == APH_GRAD_PATCH_F16) x = (float)(reinterpret_cast<const half_t*>(gout) + rowbase)[colj[m]];
+                else x = (reinterpret_cast<const float*>(gout) + rowbase)[colj[m]];
+              }
+              v[m][r] = x;
+            }
           }
-          float v[2][JT][4];
+          f32x4 u[JT];
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+          for (int m = 0; m < JT; ++m) u[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < JT; ++m) {
-              const int j = lane + 64 * m;
-              const size_t gj = gb[h] + grad_colpart<OUT>(j < g.size ? j : 0, g.size, g.patch);
+          for (int r = 0; r < 8; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(qtab[pq * 8 + r].w);
 #pragma unroll
-              for (int a = 0; a < 4; ++a) v[h][m][a] = (e[h].w[a] != 0.f && j < g.size) ? gload<OUT>(gout, gj + e[h].off[a]) : 0.f;
-            }
+            for (int m = 0; m < JT; ++m) u[m] += w * v[m][r];
+          }
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int m = 0; m < JT; ++m) {
-              u[h][m] = 0.f;
-#pragma unroll
-              for (int a = 0; a < 4; ++a) u[h][m] += e[h].w[a] * v[h][m][a];
-              const int j = lane + 64 * m;
-              if (bq[h][0] >= 0 && j < g.size) U[((size_t)bq[h][0] * g.size + j) * RBP + bq[h][1]] = u[h][m];
-            }
+          for (int m = 0; m < JT; ++m) {
+            const int j = lane + 64 * m;
+            if (j < g.size) *reinterpret_cast<f32x4*>(U + ((size_t)b * g.size + j) * RBP + 4 * qq) = u[m];
+          }
         }
       }
       __syncthreads();
+      if (b0 + NBC < nlist) phase0(b0 + NBC, cur ^ 1);
       // ---- phase 2: row pass, cuts in list order
       if (!(dbg & 2)) {
+        // four cuts x CPT columns at a time: the first offset and the four weights of every column-tap entry (20 of its 32 bytes) are
+        // loaded together, then accumulated per column in list order
+#pragma unroll
+        for (int bh = 0; bh < ADJ_NBC; bh += 4) {
+          if (bh >= nb) break;
+          f32x4 cw[CPT][4];
+          int coff[CPT][4];
+#pragma unroll
+          for (int i = 0; i < CPT; ++i) {
+            const int x = i * nthr + tid;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const int b = bh + bb;
+              coff[i][bb] = -1;
+              cw[i][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (b < nb && x < g.W) {
+                const int s = binfo[4 * b], csx = binfo[4 * b + 1], p = x - binfo[4 * b + 2];
+                if (csx > 0 && p >= 0 && p < csx && p < maxcs) {
+                  const AdjEntry* ep = tab + ((size_t)s * 2 + 1) * maxcs + p;
+                  coff[i][bb] = ep->off[0];
+                  cw[i][bb] = *reinterpret_cast<const f32x4*>(ep->w);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              if (coff[i][bb] < 0) continue;
+              // the taps of an entry are CONSECUTIVE output columns (tap_table_kernel: a contiguous run from the first non-zero weight)
+              const float* u0 = U + ((size_t)(bh + bb) * g.size + grad_col_of_off<OUT>(coff[i][bb], g.patch)) * RBP;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                if (cw[i][bb][t] == 0.f) continue;
+                const float* up = u0 + t * RBP;
+#pragma unroll
+                for (int k = 0; k < RBQ; ++k) acc[i][k] += cw[i][bb][t] * *reinterpret_cast<const f32x4*>(up + 4 * k);
+              }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
           const int x = i * nthr + tid;
           if (x >= g.W) continue;
-          // four column-tap entries at a time (independent loads in flight together), then their accumulation in list order
-#pragma unroll
-          for (int bh = 0; bh < ADJ_NBC; bh += 4) {
-            if (bh >= nb) break;
-            AdjEntry ce[4];
-            int pcol[4];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              const int b = bh + bb;
-              pcol[bb] = -1;
-              if (b < nb) {
-                const int s = binfo[4 * b], csx = binfo[4 * b + 1], p = x - binfo[4 * b + 2];
-                if (csx > 0 && p >= 0 && p < csx && p < maxcs) {
-                  pcol[bb] = p;
-                  ce[bb] = tab[((size_t)s * 2 + 1) * maxcs + p];
-                }
-              }
-            }
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              if (pcol[bb] < 0) continue;
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                if (ce[bb].w[t] == 0.f) continue;
-                const float* up = U + ((size_t)(bh + bb) * g.size + grad_col_of_off<OUT>(ce[bb].off[t], g.patch)) * RBP;
-#pragma unroll
-                for (int k = 0; k < RBQ; ++k) acc[i][k] += ce[bb].w[t] * *reinterpret_cast<const f32x4*>(up + 4 * k);
-              }
-            }
-          }
           // up-sampling cuts (cs < size; none at 1280x720): the per-pixel generic path of crop_resize_adjoint_kernel.  Kept out of the
           // unrolled loop above (a loop the compiler does not unroll would index ce[] at run time and move it to scratch memory); the
           // sum of such a cut is added after the batch's table-driven cuts -- a fixed order all the same.
@@ -793,20 +887,44 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
       const float rad = fabsf(cs) + fabsf(sn) + 0.02f;
       int j0 = (int)ceilf(qx - rad), j1 = (int)floorf(qx + rad), i0 = (int)ceilf(qy - rad), i1 = (int)floorf(qy + rad);
       if (rad <= 1.45f) {
-        // a rotation: the candidates fit a 3 x 3 box.  Branch-free -- every candidate's footprint is re-derived with the forward's
-        // own arithmetic, a miss gets weight 0 and a clamped address, and the 27 gathers issue together (one memory round trip
-        // instead of one per candidate)
+        // a rotation: the candidates fit a 3 x 3 box.  Branch-free: a miss gets weight 0 and a clamped address, the 27 gathers issue
+        // together (one memory round trip instead of one per candidate).  [r3] The weight of candidate (i, j) is the TENT form of the
+        // forward's bilinear footprint -- max(0, 1 - |ix - px|) * max(0, 1 - |iy - py|), with (ix, iy) from the forward's own grid
+        // arithmetic (rot_tap / make_tap), its row and column terms computed once per box row / column -- times the sampled ones-mask
+        // clamp(min(ix + 1, n - ix), 0, 1) * (same in y): identical to tap_hits * tap_mask up to one rounding of (1 - frac), at a third
+        // of the instructions.  (Time unchanged: the kernel is bound by the L1's access rate -- 27 scalar gathers per pixel, about 46
+        // cache accesses per gather instruction whatever the wave's pixel footprint, 64 x 1 and 16 x 4 measured alike; only a
+        // channel-interleaved gradient layout would cut that.)
+        const float fn = (float)n, hn = 0.5f * fn, ka = cs / hn, kb = sn / hn;
+        const int lp = is_patch<OUT>::v ? __ffs(patch) - 1 : 0, pg = n >> lp;
+        float gxj[3], gyj[3], gxi[3], gyi[3];
+        size_t rowo[3], colo[3];
+        bool iok[3], jok[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int i = i0 + t, j = j0 + t;
+          iok[t] = i >= 0 && i <= n - 1 && i <= i1;
+          jok[t] = j >= 0 && j <= n - 1 && j <= j1;
+          const int ic = i < 0 ? 0 : (i > n - 1 ? n - 1 : i), jc = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+          const float x = -fn * 0.5f + 0.5f + (float)jc, y = -fn * 0.5f + 0.5f + (float)ic;
+          gxj[t] = x * ka; gyj[t] = x * -kb;
+          gxi[t] = y * kb; gyi[t] = y * ka;
+          colo[t] = is_patch<OUT>::v ? (size_t)(jc >> lp) * (size_t)(3 << (2 * lp)) + (jc & (patch - 1)) : (size_t)jc;
+          rowo[t] = is_patch<OUT>::v ? (size_t)(ic >> lp) * pg * (size_t)(3 << (2 * lp)) + ((ic & (patch - 1)) << lp) : (size_t)ic * n;
+        }
+        const size_t base = is_patch<OUT>::v ? (size_t)s * pg * pg * (size_t)(3 << (2 * lp)) : (size_t)s * 3 * n * n;
+        const float fpx = (float)px, fpy = (float)py;
         float wm[9];
         size_t off[9];
 #pragma unroll
         for (int d = 0; d < 9; ++d) {
-          const int i = i0 + d / 3, j = j0 + d % 3;
-          const bool ok = i >= 0 && i <= n - 1 && j >= 0 && j <= n - 1 && i <= i1 && j <= j1;
-          const int ic = i < 0 ? 0 : (i > n - 1 ? n - 1 : i), jc = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
-          const Tap t = rot_tap(cs, sn, ic, jc, n);
-          const float w = ok ? tap_hits(t, py, px) : 0.f;
-          wm[d] = w * tap_mask(t, n);
-          off[d] = is_patch<OUT>::v ? patch_index(s, 0, ic, jc, n, patch) : ((size_t)s * 3 * n + ic) * n + jc;
+          const int a3 = d / 3, b3 = d % 3;
+          const float gx = gxj[b3] + gxi[a3], gy = gyj[b3] + gyi[a3];
+          const float ix = ((gx + 1.f) * fn - 1.f) * 0.5f, iy = ((gy + 1.f) * fn - 1.f) * 0.5f;
+          const float wx = fmaxf(0.f, 1.f - fabsf(ix - fpx)), wy = fmaxf(0.f, 1.f - fabsf(iy - fpy));
+          const float mx = fminf(fmaxf(fminf(ix + 1.f, fn - ix), 0.f), 1.f), my = fminf(fmaxf(fminf(iy + 1.f, fn - iy), 0.f), 1.f);
+          wm[d] = (iok[a3] && jok[b3]) ? (wx * wy) * (mx * my) : 0.f;
+          off[d] = base + rowo[a3] + colo[b3];
         }
         const size_t cstride = is_patch<OUT>::v ? (size_t)patch * patch : (size_t)n * n;
         float gv[9][3];
@@ -967,7 +1085,7 @@ size_t tab_bytes(const Geom& g) {
 }
 size_t scratch_floats(const Geom& g) { return (size_t)g.S * 4 * g.size * g.size; }     // HWC4 in the forward; the adjoint uses 3/4 of it, planar
 // per-XCD unit lists of the forward: [8][cap] + [8] ints
-int strip_cap(const Geom& g) { return g.S * ((g.size + 3) / 4); }
+int strip_cap(const Geom& g) { return g.S * ((g.size + kUnitRows - 1) / kUnitRows); }
 size_t strip_bytes(const Geom& g) { return ((size_t)(8 * (size_t)strip_cap(g) + 8) * sizeof(int) + 255) & ~(size_t)255; }
 
 template <int OUT>
@@ -975,7 +1093,7 @@ void launch_crop_resize(const float* rgb, const int* table, void* out, const Geo
   // ws: [tap tables | strip lists | ...]
   int* lists = reinterpret_cast<int*>(static_cast<char*>(ws) + tab_bytes(g));
   int* counts = lists + 8 * (size_t)strip_cap(g);
-  APH_LAUNCH(strip_list_kernel, dim3(1), dim3(1024), 0, st, table, lists, counts, strip_cap(g), g);
+  APH_LAUNCH(strip_list_kernel, dim3(1), dim3(1024), 0, st, table, lists, counts, strip_cap(g), g, kStripPx);
   APH_LAUNCH(crop_resize_strips_kernel<OUT>, dim3(8 * kStripSlots), dim3(256), 0, st, rgb, table, out, g, (const int*)lists, (const int*)counts, strip_cap(g));
 }
 
@@ -999,7 +1117,7 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
     rb = rb < 4 ? 4 : (rb > 16 ? 16 : rb);
     const int rbq = rb <= 12 ? 3 : 4, rbp = rbq * 4;
     int nbc = ADJ_NBC;
-    auto lds = [&](int n) { return (size_t)n * g.size * rbp * 4 + (size_t)n * rbp * sizeof(AdjEntry) + (size_t)n * 16 + 1024 * 4 + 16; };
+    auto lds = [&](int n) { return (size_t)n * g.size * rbp * 4 + 2 * (size_t)n * rbq * 8 * sizeof(QuadRow) + 2 * (size_t)n * 16 + 512 * 16 + 16; };
     while (nbc > 1 && lds(nbc) > 150 * 1024) --nbc;
     if (lds(nbc) <= 150 * 1024) {
       const dim3 rgrid((g.H + rb - 1) / rb, 3);

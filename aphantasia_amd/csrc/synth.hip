@@ -122,15 +122,17 @@ __device__ void fft_pass_large(const float2* src, float2* dst, int N, int R, int
     const int qq = o / nb, j = o - qq * nb;
     const int k = j % Ns;
     const float2* x = src + q * N;
-    float2 acc = x[j];
+    // (the R-term sum is kept in fp64: in fp32 its rounding grows with sqrt(R) -- 6e-6 on the image at R = 1307, found by tools/gpu_fuzz.py)
+    double ar = x[j].x, ai = x[j].y;
     // twiddle index of term r: r (k tscale + qq nb) mod N  (N = R nb, so (qq r mod R) nb == qq r nb mod N): one modular add per term
     const int step = (int)(((long long)k * tscale + (long long)qq * nb) % N);
     int t = 0;
     for (int r = 1; r < R; ++r) {
       t += step; if (t >= N) t -= N;
-      acc = cadd(acc, cmul(x[j + r * nb], twiddle<SIGN>(tw, t)));
+      const float2 pr = cmul(x[j + r * nb], twiddle<SIGN>(tw, t));
+      ar += pr.x; ai += pr.y;
     }
-    dst[q * N + (j / Ns) * Ns * R + k + qq * Ns] = acc;
+    dst[q * N + (j / Ns) * Ns * R + k + qq * Ns] = make_float2((float)ar, (float)ai);
   }
 }
 
