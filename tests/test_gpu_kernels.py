@@ -100,8 +100,8 @@ def test_attention_alone_vs_torch():
 
 def test_crop_adjoint_rows_kernel_vs_gather_kernel_full_size():
     """[r3] the separable row-block crop adjoint (frames without wrap padding) against the round-2 per-pixel gather kernel at the headline
-    geometry (1280x720, 190 cuts, patch-major gradient; and the planar layout the -tf fast chain hands it), plus 4K width (4 columns per
-    thread); same bits on every launch"""
+    geometry (1280x720, 190 cuts, patch-major gradient; and the planar layout the -tf fast chain hands it), a small odd frame, and 4K width
+    (W > 2304: the launcher keeps the gather kernel there); same bits on every launch -- the tripwire for the kernel's double-buffered tables"""
     import numpy as np
     import torch
     from aphantasia_amd import ops
