@@ -797,6 +797,10 @@ __device__ __forceinline__ bool in_rect(const float* __restrict__ a, int y, int 
 
 // sampled value (three channels of one HWC4 cut image) times sampled ones-mask (fill = 0); ERASE: source pixels inside the
 // erase rectangle read as 0
+// warp_block_note [r3]: a workgroup of the four warp kernels covers 32 x 8 pixels (it was 64 x 4).  Under a rotation the taps of a
+// 64 x 4 strip cross ~32 gradient rows and use a few pixels of every 128-byte line they touch, and the neighbouring strips that use
+// the rest run on other XCDs: rotate_emit_adjoint measured 353 MB of L2 misses per launch for a 114 MB gradient.  A squarer tile
+// shares fewer lines with its neighbours: augment adjoints 178-188 -> 154-162 us, forward chain 225 -> 217 us (16 x 16 measured the same).
 template <bool ERASE>
 __device__ __forceinline__ void warp_gather3(const float* __restrict__ src, const Tap& t, int n, const float* __restrict__ a, float v[3]) {
   // branch-free: out-of-range taps read a clamped address with weight 0, so the four 16-byte loads issue together
@@ -823,7 +827,7 @@ __global__ void persp_kernel(const float* __restrict__ A, const float* __restric
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31), i = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (i >= n || j >= n) return;
   const Tap t = persp_tap(a, i, j, n);
   float v[3];
@@ -837,7 +841,7 @@ __global__ void rotate_emit_kernel(const float* __restrict__ A, const float* __r
                                    void* __restrict__ out, int n, int patch) {
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31), i = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (i >= n || j >= n) return;
   const float* src = (a[8] != 0.f ? Bi : A) + hwc4_index(s, 0, 0, n);
   float v[3];
@@ -874,7 +878,7 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
                                            float* __restrict__ dA, float* __restrict__ dB, int n, int patch) {
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
-  const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int px = blockIdx.x * 32 + (threadIdx.x & 31), py = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (py >= n || px >= n) return;
   float* dst = a[8] != 0.f ? dB : dA;
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -966,7 +970,7 @@ __global__ void persp_adjoint_kernel(const float* __restrict__ dB, const float* 
   const int s = blockIdx.z;
   const float* a = aug + (size_t)s * APH_AUG_STRIDE;
   if (a[8] == 0.f) return;
-  const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int px = blockIdx.x * 32 + (threadIdx.x & 31), py = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (py >= n || px >= n) return;
     // forward: (u, v) = H (x, y), x = j + .5, y = i + .5, source index = (u - .5, v - .5);  adj(H) maps back
   const float m00 = a[4] - a[5] * a[7], m01 = a[2] * a[7] - a[1], m02 = a[1] * a[5] - a[2] * a[4];
@@ -1165,7 +1169,7 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   hipStream_t st = (hipStream_t)stream_;
   const Geom g = to_geom(gg);
   const int n = g.size;
-  const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S), block(256);       // thread = (column, row) of a cut: 64 x 4 pixels per workgroup
+  const dim3 grid((n + 31) / 32, (n + 7) / 8, g.S), block(256);       // thread = (column, row) of a cut: 32 x 8 pixels per workgroup (warp_block_note)
   if (!aug) {
     if (out_mode == APH_OUT_NCHW_RAW) launch_crop_resize<APH_OUT_NCHW_RAW>(rgb, (const int*)table, out, g, ws, st);
     else if (out_mode == APH_OUT_NCHW_NORM) launch_crop_resize<APH_OUT_NCHW_NORM>(rgb, (const int*)table, out, g, ws, st);
@@ -1205,7 +1209,7 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
   }
   float* dA = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g) + strip_bytes(g));
   float* dB = dA + scratch_floats(g);
-  const dim3 grid((n + 63) / 64, (n + 3) / 4, g.S);
+  const dim3 grid((n + 31) / 32, (n + 7) / 8, g.S);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
   else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_adjoint_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, gout, aug, dA, dB, n, g.patch);
