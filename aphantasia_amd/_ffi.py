@@ -43,6 +43,8 @@ _PROTOTYPES = {
     'aph_rgb_sharp': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_rgb_priors': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_idwt_level_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    'aph_idwt_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'aph_idwt_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_idwt_level_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'aph_sample_ws_bytes': (c_size_t, [POINTER(SampleGeom), c_int]),
     'aph_sample_fwd': (c_int, [POINTER(SampleGeom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

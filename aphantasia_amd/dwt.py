@@ -3,8 +3,9 @@
 All coefficient tensors live in ONE flat fp32 buffer (Yl, then every detail level, finest first -- the order
 of the reference's `Ys` list); the per-tensor views handed to Python share that storage, so the fused engine
 can run Adam and the multi-GPU all-reduce on the flat buffer while `torch.save(Ys)` / torch.optim keep working.
-The inverse transform is one HIP launch per level (csrc/dwt.hip), coarsest first.
+The inverse transform is one C-ABI call (csrc/dwt.hip): one launch per level, coarsest first, the single-tile coarse tail in one launch.
 """
+import ctypes
 import math
 
 import torch
@@ -100,8 +101,27 @@ class DWTSynth:
     def views(self, flat):
         return [flat[o:o + math.prod(s)].view(s) for o, s in zip(self.offsets, self.shapes)]
 
+    def _level_arrays(self):
+        """host-side size / gain arrays of the all-levels calls (built once)"""
+        if getattr(self, '_lv', None) is None:
+            J = self.J
+            IntJ, FltJ, PtrJ = ctypes.c_int * J, ctypes.c_float * J, ctypes.c_void_p * J
+            self._lv = dict(hs=IntJ(*[s[0] for s in self.sizes]), ws=IntJ(*[s[1] for s in self.sizes]),
+                            sc=FltJ(*[float(v) for v in self.scale]), bufs=PtrJ(*[b.data_ptr() for b in self.bufs]),
+                            gbufs=PtrJ(*[b.data_ptr() for b in self.gbufs]), PtrJ=PtrJ)
+        return self._lv
+
     def forward(self, flat):
-        """flat coefficient buffer -> raw image [C, H, W] (the tensor is owned by this object)"""
+        """flat coefficient buffer -> raw image [C, H, W] (the tensor is owned by this object): every level in one C-ABI call"""
+        ys = self.views(flat)
+        lv = self._level_arrays()
+        highs = lv['PtrJ'](*[y.data_ptr() for y in ys[1:]])
+        self.lib.call('aph_idwt_fwd', ops.ptr(ys[0]), highs, lv['hs'], lv['ws'], lv['sc'], self.J, self.C, ops.ptr(self.g0), ops.ptr(self.g1),
+                      self.L, lv['bufs'], ops._stream(flat))
+        return self.bufs[0]
+
+    def forward_per_level(self, flat):
+        """the same transform as one aph_idwt_level_fwd call per level (tests and per-level timing: tools/exp/dwt_levels.py)"""
         ys = self.views(flat)
         st = ops._stream(flat)
         ll, llh, llw = ys[0], self.sizes[-1][0], self.sizes[-1][1]
@@ -112,8 +132,7 @@ class DWTSynth:
             ll, (llh, llw) = self.bufs[j], self.out_sizes[j]
         return self.bufs[0]
 
-    def backward(self, d_raw, grad_flat):
-        """d_raw [C,H,W] -> gradient w.r.t. every coefficient, written into grad_flat (same layout as the params)"""
+    def backward_per_level(self, d_raw, grad_flat):
         gs = self.views(grad_flat)
         st = ops._stream(grad_flat)
         g = d_raw
@@ -126,4 +145,15 @@ class DWTSynth:
             self.lib.call('aph_idwt_level_bwd', ops.ptr(g), hh, ww, self.C, ops.ptr(self.g0), ops.ptr(self.g1), self.L,
                           float(self.scale[j]), ops.ptr(dst), llh, llw, ops.ptr(gs[1 + j]), st)
             g = dst
+        return grad_flat
+
+    def backward(self, d_raw, grad_flat):
+        """d_raw [C,H,W] -> gradient w.r.t. every coefficient, written into grad_flat (same layout as the params)"""
+        gs = self.views(grad_flat)
+        lv = self._level_arrays()
+        ghighs = lv['PtrJ'](*[g.data_ptr() for g in gs[1:]])
+        if not d_raw.is_contiguous() or tuple(d_raw.shape[-2:]) != (self.H, self.W):
+            raise ValueError('d_raw must be a contiguous [C,%d,%d] tensor' % (self.H, self.W))
+        self.lib.call('aph_idwt_bwd', ops.ptr(d_raw), lv['hs'], lv['ws'], lv['sc'], self.J, self.C, ops.ptr(self.g0), ops.ptr(self.g1), self.L,
+                      lv['gbufs'], ops.ptr(gs[0]), ghighs, ops._stream(grad_flat))
         return grad_flat

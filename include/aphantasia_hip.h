@@ -88,6 +88,19 @@ int aph_idwt_level_fwd(const float* d_ll, int ll_h, int ll_w, const float* d_hig
 int aph_idwt_level_bwd(const float* d_out_grad, int h, int w, int C, const float* d_g0, const float* d_g1, int L,
                        float hscale, float* d_ll_grad, int ll_h, int ll_w, float* d_highs_grad, void* stream);
 
+/* Every level of DWTInverse in one call (what dwt_image.inner runs per step, image.py:36-38,67).  Host arrays of J entries,
+ * level 0 = finest: hs / ws = size of the level's detail bands, hscales = dwt_scale gains (image.py:73-80), d_highs[j]
+ * [C,3,hs[j],ws[j]] (device pointers), d_bufs[j] [C, 2 hs[j]-L+2, 2 ws[j]-L+2] = the running low band after level j
+ * (caller-owned scratch; d_bufs[0] receives the image).  d_yl [C, hs[J-1], ws[J-1]] = the coarsest low band.
+ * The levels whose output is a single tile run in one launch (APH_IDWT_COARSE=0: one launch per level). */
+int aph_idwt_fwd(const float* d_yl, const float* const* d_highs, const int* hs, const int* ws, const float* hscales, int J,
+                 int C, const float* d_g0, const float* d_g1, int L, float* const* d_bufs, void* stream);
+/* adjoint: d_img_grad [C, 2 hs[0]-L+2, 2 ws[0]-L+2] -> d_highs_grad[j] [C,3,hs[j],ws[j]] and d_yl_grad [C,hs[J-1],ws[J-1]];
+ * d_gbufs[j] (j >= 1) = scratch of d_bufs[j]'s size (d_gbufs[0] is not used). */
+int aph_idwt_bwd(const float* d_img_grad, const int* hs, const int* ws, const float* hscales, int J, int C,
+                 const float* d_g0, const float* d_g1, int L, float* const* d_gbufs, float* d_yl_grad,
+                 float* const* d_highs_grad, void* stream);
+
 /* ---- sampler: aphantasia/utils.py:218-254 slice_imgs + transforms.py:102-109,165-170 ------- */
 /* Geometry of one slice_imgs call.  (Hp,Wp,py0,px0) describe the wrap-tiled overscan frame of
  * pad_up_to/tile_pad (utils.py:152-187); Hp=H, Wp=W, py0=px0=0 when align has no 'over'. */

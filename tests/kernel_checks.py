@@ -117,6 +117,18 @@ def check_dwt(lib, dev, wave, h, w, sharp=0.3, colors=1.5, contrast=1.1):
     syn.backward(d_raw, grad)
     ref = torch.cat([y.grad.reshape(-1) for y in Ys])
     assert (grad.cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+    # one launch per level (aph_idwt_level_*) computes the same sums in the same order as the all-levels calls, whose coarse
+    # tail runs in one launch (bit-identical under the interpreter; on the GPU the two instantiations may contract their
+    # multiply-adds differently, so a rounding-level tolerance there)
+    raw1 = raw.clone()
+    raw2 = syn.forward_per_level(flat)
+    grad1 = torch.full_like(flat, float('nan'))
+    syn.backward_per_level(d_raw, grad1)
+    if dev == 'cpu':
+        assert torch.equal(raw2, raw1) and torch.equal(grad1, grad)
+    else:
+        assert (raw2 - raw1).abs().max().item() <= 1e-6 * raw1.abs().max().item()
+        assert (grad1 - grad).abs().max().item() <= 1e-6 * grad.abs().max().item()
 
 
 def check_sampler_golden(lib, dev, g, align):

@@ -33,6 +33,9 @@ def test_synth_oracle_shift_and_odd_radix(emu):
 def test_dwt(emu):
     K.check_dwt(emu, 'cpu', 'db3', 45, 70)          # odd sizes: the dropped row/col path
     K.check_dwt(emu, 'cpu', 'coif2', 64, 96)
+    K.check_dwt(emu, 'cpu', 'db3', 48, 72)          # rows of 4 outputs per lane (16-byte stores) in the finest level
+    K.check_dwt(emu, 'cpu', 'db2', 40, 56)
+    K.check_dwt(emu, 'cpu', 'db5', 50, 60)          # run-time filter length: the generic row-loop loads
 
 
 def test_fft_pair(emu):
