@@ -160,6 +160,8 @@ __device__ float2* fft_lds(float2* a, float2* b, const Fft1D& plan, int nseq, co
   return a;
 }
 
+constexpr int kLoadBatch = 8;      // items per thread whose global loads are in flight together in the passes' load phases
+
 // ---------------------------------------------------------------------------------
 // column pass, forward synthesis: tmp[c][y][kx] = sum_ky scale*params[c][ky][kx] e^{+2 pi i ky y/H}
 // ---------------------------------------------------------------------------------
@@ -170,17 +172,36 @@ __global__ void fft_col_synth_kernel(const float2* __restrict__ params, const fl
   float2* a = reinterpret_cast<float2*>(smem);
   float2* b = a + TC * H;
   const int g0 = blockIdx.x * TC, G = C * Wc;
-  for (int idx = threadIdx.x; idx < TC * H; idx += blockDim.x) {
-    const int t = idx % TC, ky = idx / TC, g = g0 + t;
-    float2 v = make_float2(0.f, 0.f);
-    if (g < G) {
-      const int c = g / Wc, kx = g - c * Wc;
-      const float s = scale ? scale[ky * Wc + kx] : 1.0f;
-      v = params[((size_t)c * H + ky) * Wc + kx];
-      v.x *= s; v.y *= s;
-      if (shift) { const float sh = s * shift[ky * Wc + kx]; v.x += sh; v.y += sh; }
+  // kLoadBatch items per thread with all their loads issued before the first LDS write (clamped addresses, the value masked
+  // afterwards): one memory round trip per batch instead of one per item
+  for (int base = 0; base < TC * H; base += kLoadBatch * blockDim.x) {
+    float2 v[kLoadBatch];
+    float sc[kLoadBatch], sf[kLoadBatch];
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      const int t = idx % TC, ky = idx / TC, g = g0 + t;
+      const bool ok = idx < TC * H && g < G;
+      const int c = ok ? g / Wc : 0, kx = ok ? g - c * Wc : 0, kyc = ok ? ky : 0;
+      v[u] = params[((size_t)c * H + kyc) * Wc + kx];
+      sc[u] = scale ? scale[kyc * Wc + kx] : 1.0f;
+      sf[u] = shift ? shift[kyc * Wc + kx] : 0.f;
     }
-    a[t * H + ky] = v;
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      const int t = idx % TC, ky = idx / TC, g = g0 + t;
+      if (idx < TC * H) {
+        float2 w = make_float2(0.f, 0.f);
+        if (g < G) {
+          const float s = sc[u];
+          w = v[u];
+          w.x *= s; w.y *= s;
+          if (shift) { const float sh = s * sf[u]; w.x += sh; w.y += sh; }
+        }
+        a[t * H + ky] = w;
+      }
+    }
   }
   __syncthreads();
   const float2* r = fft_lds<+1>(a, b, plan, TC, tw);
@@ -201,14 +222,22 @@ __global__ void fft_col_adjoint_kernel(const float2* __restrict__ tmp, const flo
   float2* a = reinterpret_cast<float2*>(smem);
   float2* b = a + TC * H;
   const int g0 = blockIdx.x * TC, G = C * Wc;
-  for (int idx = threadIdx.x; idx < TC * H; idx += blockDim.x) {
-    const int t = idx % TC, y = idx / TC, g = g0 + t;
-    float2 v = make_float2(0.f, 0.f);
-    if (g < G) {
-      const int c = g / Wc, kx = g - c * Wc;
-      v = tmp[((size_t)c * H + y) * Wc + kx];
+  for (int base = 0; base < TC * H; base += kLoadBatch * blockDim.x) {      // (batched loads: see fft_col_synth_kernel)
+    float2 v[kLoadBatch];
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      const int t = idx % TC, y = idx / TC, g = g0 + t;
+      const bool ok = idx < TC * H && g < G;
+      const int c = ok ? g / Wc : 0, kx = ok ? g - c * Wc : 0;
+      v[u] = tmp[((size_t)c * H + (ok ? y : 0)) * Wc + kx];
     }
-    a[t * H + y] = v;
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      const int t = idx % TC, y = idx / TC, g = g0 + t;
+      if (idx < TC * H) a[t * H + y] = g < G ? v[u] : make_float2(0.f, 0.f);
+    }
   }
   __syncthreads();
   const float2* r = fft_lds<-1>(a, b, plan, TC, tw);
@@ -240,15 +269,28 @@ __global__ void fft_row_synth_kernel(const float2* __restrict__ tmp, float* __re
   const bool has1 = y1 < H;
   const float2* ra = tmp + ((size_t)c * H + y0) * Wc;
   const float2* rb = tmp + ((size_t)c * H + (has1 ? y1 : y0)) * Wc;
-  for (int k = threadIdx.x; k < Wc; k += blockDim.x) {
-    float2 A = ra[k];
-    float2 Bv = has1 ? rb[k] : make_float2(0.f, 0.f);
-    const bool edge = (k == 0) || (2 * k == W);   // DC / Nyquist: imaginary part ignored (C2R)
-    if (edge) {
-      a[k] = make_float2(A.x, Bv.x);
-    } else {
-      a[k] = make_float2(A.x - Bv.y, A.y + Bv.x);
-      a[W - k] = make_float2(A.x + Bv.y, Bv.x - A.y);
+  for (int base = 0; base < Wc; base += kLoadBatch * blockDim.x) {      // (batched loads: see fft_col_synth_kernel)
+    float2 Av[kLoadBatch], Bw[kLoadBatch];
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int k = base + u * blockDim.x + threadIdx.x, kc = k < Wc ? k : 0;
+      Av[u] = ra[kc];
+      Bw[u] = rb[kc];
+    }
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int k = base + u * blockDim.x + threadIdx.x;
+      if (k < Wc) {
+        const float2 A = Av[u];
+        const float2 Bv = has1 ? Bw[u] : make_float2(0.f, 0.f);
+        const bool edge = (k == 0) || (2 * k == W);   // DC / Nyquist: imaginary part ignored (C2R)
+        if (edge) {
+          a[k] = make_float2(A.x, Bv.x);
+        } else {
+          a[k] = make_float2(A.x - Bv.y, A.y + Bv.x);
+          a[W - k] = make_float2(A.x + Bv.y, Bv.x - A.y);
+        }
+      }
     }
   }
   __syncthreads();
@@ -283,10 +325,24 @@ __global__ void fft_row_adjoint_kernel(const float* __restrict__ dn, const float
   // plain: the forward transform rfft2 itself (aph_rfft2) -- no normalisation adjoint, no doubling of interior columns
   const float A = plain ? 1.0f : bstats[0], Bc = plain ? 0.0f : bstats[1], mu = plain ? 0.0f : bstats[2];
   const size_t o0 = ((size_t)c * H + y0) * W, o1 = ((size_t)c * H + y1) * W;
-  for (int x = threadIdx.x; x < W; x += blockDim.x) {
-    const float g0 = A * dn[o0 + x] + Bc * (raw[o0 + x] - mu);
-    const float g1 = has1 ? A * dn[o1 + x] + Bc * (raw[o1 + x] - mu) : 0.f;
-    a[x] = make_float2(g0, g1);
+  const size_t o1c = has1 ? o1 : o0;
+  for (int base = 0; base < W; base += kLoadBatch * blockDim.x) {      // (batched loads: see fft_col_synth_kernel)
+    float d0[kLoadBatch], r0[kLoadBatch], d1[kLoadBatch], r1[kLoadBatch];
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int x = base + u * blockDim.x + threadIdx.x, xc = x < W ? x : 0;
+      d0[u] = dn[o0 + xc]; r0[u] = raw[o0 + xc];
+      d1[u] = dn[o1c + xc]; r1[u] = raw[o1c + xc];
+    }
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int x = base + u * blockDim.x + threadIdx.x;
+      if (x < W) {
+        const float g0 = A * d0[u] + Bc * (r0[u] - mu);
+        const float g1 = has1 ? A * d1[u] + Bc * (r1[u] - mu) : 0.f;
+        a[x] = make_float2(g0, g1);
+      }
+    }
   }
   __syncthreads();
   const float2* r = fft_lds<-1>(a, b, plan, 1, tw);

@@ -127,28 +127,34 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
   v->prof_flops += 2.0 * M * N * K;
 }
 
+// g2 / b2 / out2: the next LayerNorm of the same rows fused behind this one (ln_fwd_kernel)
 template <bool OUT_F16, bool CLS>
 void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void* out, int M, int T, const float* cls,
-                   const float* pos, float* x_fill, hipStream_t st, int xs = 1) {
+                   const float* pos, float* x_fill, hipStream_t st, int xs = 1, const float* g2 = nullptr, const float* b2 = nullptr,
+                   half_t* out2 = nullptr) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
-    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
-    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
-    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs); break;
+    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
+    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
+    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
+    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
   }
 }
+// res_T: residual on the rows with row % res_T == 0 only;  x_b / g_b: the previous LayerNorm's backward fused behind this one (ln_bwd_kernel)
 template <bool DY_F16, bool PATCH>
 void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const float* res, float* out32, half_t* out16, int M,
-                   int T, hipStream_t st, int xs = 1) {
+                   int T, hipStream_t st, int xs = 1, int res_T = 0, const float* x_b = nullptr, const float* g_b = nullptr) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
-    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
-    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
-    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs); break;
+    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
+    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
+    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
+    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
   }
 }
+// LayerNorm pairs of the first block as one kernel each way, and no zero fill of the fp32 gradient stream (APH_VIT_FUSE_LN=0 or
+// aph_vit_set_fuse_ln(0): the separate kernels -- bit-identical, kept for A/B runs and the equivalence test)
+int g_fuse_ln = [] { const char* e = getenv("APH_VIT_FUSE_LN"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // attention launches: T <= 64 one-tile kernels, 64 < T <= 256 the blocked kernels (NB = ceil(T / 64))
 struct AttnArgs {
@@ -312,11 +318,13 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   vgemm(v, (const half_t*)d_patches, v->Kp, v->w_patch, v->Kp, S * v->P, D, v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
-  launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st);
+  const bool fuse = g_fuse_ln != 0;
+  launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st, 1,
+                             fuse ? v->layers[0].ln1_g : nullptr, fuse ? v->layers[0].ln1_b : nullptr, fuse ? v->h : nullptr);
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
-    launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
+    if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
     vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
     launch_attn_fwd(attn_args(v, l, S), st);
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
@@ -343,7 +351,8 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
   // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
-  zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
+  const bool fuse = g_fuse_ln != 0;      // (then the last block's ln_1 backward takes its residual from the class rows only: no fill)
+  if (!fuse) zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
   for (int li = v->L - 1; li >= 0; --li) {
@@ -357,9 +366,12 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
     vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
     launch_attn_bwd(attn_args(v, l, S), st);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
-    launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st);
+    if (fuse && li == 0)      // ln_1 backward and ln_pre backward as one kernel: writes the patch rows of dx0_16 only
+      launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, nullptr, v->dx0_16, M, T, st, 1, cls_only ? T : 0, v->x0, v->ln_pre_g);
+    else
+      launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st, 1, (fuse && cls_only) ? T : 0);
   }
-  launch_ln_bwd<false, true>(nv, v->dx, v->x0, v->ln_pre_g, nullptr, nullptr, v->dx0_16, M, T, st);
+  if (!fuse) launch_ln_bwd<false, true>(nv, v->dx, v->x0, v->ln_pre_g, nullptr, nullptr, v->dx0_16, M, T, st);
   if (grad_f16) vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF16Scale{(half_t*)d_patch_grad, v->Kp, out_scale}, st);
   else vgemm(v, v->dx0_16, D, v->w_patchT, D, S * v->P, v->Kp, D, EpiF32{(float*)d_patch_grad, v->Kp, out_scale}, st);
   return aph_check_launch("aph_vit_backward");
@@ -402,6 +414,13 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
 }
 
 // MFMA shape of every GEMM main loop launched from now on: 0 = 16x16x32 (default), 1 = 32x32x16.  Returns the previous value.
+// LayerNorm fusions of the first / last block on (1, default) or off (0).  Returns the previous value.
+int aph_vit_set_fuse_ln(int on) {
+  const int prev = g_fuse_ln;
+  g_fuse_ln = on ? 1 : 0;
+  return prev;
+}
+
 int aph_gemm_set_mfma32(int on) {
   const int prev = gemm_mfma32();
   gemm_mfma32() = on ? 1 : 0;

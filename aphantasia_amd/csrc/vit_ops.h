@@ -17,10 +17,14 @@ constexpr int kHeadDim = 64;
 // CLS_FILL: row t == 0 of every image is read as class_embedding + pos[0] (the patch-embed GEMM
 //           only writes token rows 1..T-1) -- used by ln_pre.
 // ---------------------------------------------------------------------------------
+// gamma2 != NULL (fp32 output only): the NEXT LayerNorm of the same rows is applied to the row just produced, from registers:
+//           out2 = f16 LN(out; gamma2, beta2) -- ln_pre followed by the first block's ln_1 as one kernel (the same arithmetic on
+//           the same fp32 values as the two kernels it replaces: bit-identical).
 template <int NV, bool OUT_F16, bool CLS_FILL>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                               void* __restrict__ out, int M, int T, const float* __restrict__ cls, const float* __restrict__ pos,
-                              float* __restrict__ x_fill, int xs) {
+                              float* __restrict__ x_fill, int xs, const float* __restrict__ gamma2 = nullptr,
+                              const float* __restrict__ beta2 = nullptr, half_t* __restrict__ out2 = nullptr) {
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -59,6 +63,29 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
       *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(out) + (size_t)row * D + d) = h;
     } else {
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)row * D + d) = o;
+      v[i] = o;
+    }
+  }
+  if (!OUT_F16 && gamma2) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s2 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean2 = wave_sum(s2) * (1.0f / D);
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float c = v[i][j] - mean2; q2 += c * c; }
+    const float rstd2 = rsqrtf(wave_sum(q2) * (1.0f / D) + kLnEps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = i * 256 + lane * 4;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma2 + d), b = *reinterpret_cast<const f32x4*>(beta2 + d);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean2) * rstd2 * g[j] + b[j];
+      half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+      *reinterpret_cast<half4*>(out2 + (size_t)row * D + d) = h;
     }
   }
 }
@@ -68,10 +95,15 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // gradient (fp32) or NULL.  Writes fp32 (out32, optional) and/or f16 (out16, optional).
 // PATCH_ROWS: out16 row index is compacted s*T + t -> s*(T-1) + t-1 and class rows are dropped
 // (feeds the patch-embedding dgrad GEMM).
+// res_T > 0: only the rows with row % res_T == 0 have a residual (the last block saw class rows only, so the fp32 gradient
+//           stream it hands to its ln_1 holds nothing else -- and need not be zero-filled first).
+// x_b != NULL (not with PATCH_ROWS): the row just produced is at once the dy of the PREVIOUS LayerNorm over the same rows (input x_b,
+//           gain gamma_b): that one's input-gradient goes to out16 in the PATCH_ROWS layout and nothing else is written -- the first
+//           block's ln_1 backward followed by ln_pre's as one kernel (the same arithmetic on the same fp32 values: bit-identical).
 template <int NV, bool DY_F16, bool PATCH_ROWS>
 __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ res, float* __restrict__ out32, half_t* __restrict__ out16, int M, int T,
-                              int xs) {
+                              int xs, int res_T = 0, const float* __restrict__ x_b = nullptr, const float* __restrict__ gamma_b = nullptr) {
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -120,11 +152,50 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - sg - v[i][j] * sgx);
-    if (res) o += *reinterpret_cast<const f32x4*>(res + srow * D + d);
+    if (res && (res_T == 0 || row % res_T == 0)) o += *reinterpret_cast<const f32x4*>(res + srow * D + d);
+    if (!PATCH_ROWS && x_b) { g[i] = o; continue; }
     if (out32) *reinterpret_cast<f32x4*>(out32 + srow * D + d) = o;
     if (out16) {
       half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
       *reinterpret_cast<half4*>(out16 + orow * D + d) = h;
+    }
+  }
+  if (!PATCH_ROWS && x_b) {
+    // second LayerNorm backward, dy = g[] (fp32), exactly ln_bwd_kernel<NV, false, true>(g, x_b, gamma_b, res = NULL)
+    const int s_ = row / T, t_ = row - s_ * T;
+    if (t_ == 0) return;
+    const size_t prow = (size_t)s_ * (T - 1) + t_ - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = i * 256 + lane * 4;
+      v[i] = *reinterpret_cast<const f32x4*>(x_b + srow * D + d);
+      g[i] = g[i] * *reinterpret_cast<const f32x4*>(gamma_b + d);
+    }
+    float sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sb += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean_b = wave_sum(sb) * (1.0f / D);
+    float qb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][j] -= mean_b; qb += v[i][j] * v[i][j]; }
+    const float rstd_b = rsqrtf(wave_sum(qb) * (1.0f / D) + kLnEps);
+    float sgb = 0.f, sgxb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][j] *= rstd_b; sgb += g[i][j]; sgxb += g[i][j] * v[i][j]; }
+    sgb = wave_sum(sgb) * (1.0f / D);
+    sgxb = wave_sum(sgxb) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = i * 256 + lane * 4;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd_b * (g[i][j] - sgb - v[i][j] * sgxb);
+      half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+      *reinterpret_cast<half4*>(out16 + prow * D + d) = h;
     }
   }
 }

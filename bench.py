@@ -178,15 +178,31 @@ def lib_sha():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+GEMM_SOURCES = ('aph_device.h', 'aph_host.h', 'vit_gemm.h', 'vit_gemm_ws.h', 'vit_attn.h', 'vit_ops.h', 'vit.hip')
+
+
+def gemm_src_sha():
+    """sha256 over the sources the ViT translation unit (every GEMM kernel) is compiled from"""
+    hsh = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(ROOT, 'aphantasia_amd', 'csrc', name), 'rb') as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()
+
+
 def pmc_traffic(tag_glob):
-    """HBM-side bytes per GEMM launch from the newest committed PMC summary (tools/pmc_traffic.py); stale unless it was
-    taken on the very library that is being timed"""
-    pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', tag_glob)), key=os.path.getmtime)
-    if not pm:
-        return None, None, None
-    with open(pm[-1]) as f:
-        j = json.load(f)
-    return j.get('traffic_bytes_per_launch'), os.path.relpath(pm[-1], ROOT), j.get('lib_sha256') != lib_sha()
+    """HBM-side bytes per GEMM launch from a committed PMC summary (tools/pmc_traffic.py).  Accepted only if it was taken on
+    the very library that is being timed, or on a library whose GEMM sources (GEMM_SOURCES) are byte-identical to this
+    checkout's -- a later change to another translation unit does not move the GEMM kernels' traffic; anything else is
+    reported as stale.  -> (bytes per launch, file, stale, what matched)"""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', tag_glob))):      # (by name: r01 < r02 < r03; mtimes mean nothing after a checkout)
+        with open(path) as f:
+            j = json.load(f)
+        match = 'library' if j.get('lib_sha256') == lib_sha() else 'gemm_sources' if j.get('gemm_src_sha256') == gemm_src_sha() else None
+        if match or best is None or best[3] is None:       # the newest matching summary, else the newest one (flagged stale)
+            best = (j.get('traffic_bytes_per_launch'), os.path.relpath(path, ROOT), match is None, match)
+    return best if best else (None, None, None, None)
 
 
 def _spawned_rank(local_rank, world, port):
@@ -362,10 +378,10 @@ def main():
             achieved = fl_t / (ms_t * 1e-3) / 1e12
             traffic, tsrc, stale = (None, None, None)
             if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1:
-                traffic, tsrc, stale = pmc_traffic('r*_pmc_hbm_traffic*.json')
+                traffic, tsrc, stale, tmatch = pmc_traffic('r*_pmc_hbm_traffic*.json')
             roof = dict(bound='mfma', kernel='aph::gemm_f16_kernel<*> / aph::gemm8_f16_kernel<*>', achieved=achieved, peak=PEAK_TF,
                         unit='TFLOP/s', frac=achieved / PEAK_TF, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
-                        traffic_source=tsrc, traffic_stale=stale, launches_per_step=n_t // nprof,
+                        traffic_source=tsrc, traffic_stale=stale, traffic_match=tmatch, launches_per_step=n_t // nprof,
                         avg_launch_us=ms_t * 1e3 / n_t, flops_per_launch=fl_t / n_t, gemm_ms_per_step=ms_t / nprof,
                         step_frac=flop_step * (a.steps / dt) / PEAK_TF,
                         step_frac_note='algorithmic_tflop_per_step x steps/s / peak (whole step, every kernel and gap included)',

@@ -43,6 +43,10 @@ int aph_crop_adjoint_set_gather(int on);
  * faster on MI355X with real operands -- the chip is power-limited there and the 32x32x16 form sustains less),
  * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
 int aph_gemm_set_mfma32(int on);
+/* the first block's LayerNorm pairs (ln_pre + ln_1 forward, ln_1 + ln_pre backward) as one kernel each and no zero fill of the
+ * fp32 gradient stream: on (1, default; APH_VIT_FUSE_LN=0 in the environment turns it off) / off (0).  Bit-identical either way.
+ * Returns the previous value.  Captured graphs keep the setting they were recorded with. */
+int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */

@@ -388,23 +388,31 @@ def check_linear_head(lib, dev):
     assert np.allclose((genc.cpu() - genc0).numpy() / 8.0, enc.grad.numpy(), rtol=1e-4, atol=2e-7)      # (difference of O(1) f32 values)
 
 
-def check_adam(lib, dev, n=5000):
+def check_adam(lib, dev, n=5000, offset=0):
+    """offset > 0: every buffer starts `offset` floats into its allocation (not 16-byte aligned: the scalar kernels)"""
     gen = torch.Generator().manual_seed(0)
+
+    def buf(t):
+        if t is None or not offset:
+            return t
+        big = torch.zeros(t.numel() + offset, device=t.device)
+        big[offset:] = t
+        return big[offset:]
     for name, kw, dec, ams in [('adam_custom', dict(beta1=0.0), False, False), ('adam', dict(beta1=0.9), False, False),
                                ('adamw', dict(beta1=0.9, weight_decay=0.01), True, False),
                                ('adamw_custom', dict(beta1=0.0, weight_decay=0.01), True, True)]:
         p0 = torch.randn(n, generator=gen)
         q = p0.clone().requires_grad_(True)
-        p = p0.to(dev)
+        p = buf(p0.to(dev))
         opt = R.make_optimizer([q], name, 0.05)
-        m = torch.zeros(n, device=dev) if kw['beta1'] else None
-        v, vm = torch.zeros(n, device=dev), (torch.zeros(n, device=dev) if ams else None)
+        m = buf(torch.zeros(n, device=dev)) if kw['beta1'] else None
+        v, vm = buf(torch.zeros(n, device=dev)), (buf(torch.zeros(n, device=dev)) if ams else None)
         for step in range(1, 4):
             grad = torch.randn(n, generator=gen) * 0.01
             q.grad = grad.clone()
             opt.step()
             hyper = torch.tensor(ops.adam_hyper(step, 0.05, **kw), dtype=torch.float32).to(dev)
-            ops.adam_step(p, grad.to(dev), m, v, vm, hyper, dec, lib=lib)
+            ops.adam_step(p, buf(grad.to(dev)), m, v, vm, hyper, dec, lib=lib)
             assert (p.cpu() - q.detach()).abs().max().item() < 2e-6, name
 
 
@@ -445,6 +453,17 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2):
     gx = ops.unpatchify(gp, S, Rr, p, lib=lib)
     berr = (gx.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
     assert berr < bwd_tol, berr
+    # the fused LayerNorm pairs of the first block (and the unfilled fp32 gradient stream) against the separate kernels: the same
+    # arithmetic on the same values, so the results are equal bit for bit
+    L = lib if lib is not None else _ffi.lib()
+    enc1, gp1 = enc.clone(), gp.clone()
+    prev = L.call('aph_vit_set_fuse_ln', 0)
+    try:
+        enc0 = vit.forward(patches, S).clone()
+        gp0 = vit.backward((genc * LS).to(dev).contiguous(), S, out_scale=1.0 / LS).clone()
+    finally:
+        L.call('aph_vit_set_fuse_ln', prev)
+    assert torch.equal(enc0, enc1) and torch.equal(gp0, gp1)
     return ferr, berr
 
 

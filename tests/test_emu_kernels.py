@@ -85,6 +85,8 @@ def test_linear_head(emu):
 
 def test_adam(emu):
     K.check_adam(emu, 'cpu')
+    K.check_adam(emu, 'cpu', n=5003)             # 16-byte quads + a scalar tail
+    K.check_adam(emu, 'cpu', n=1001, offset=1)   # unaligned buffers: the scalar kernels
 
 
 def test_gemm(emu):

@@ -86,6 +86,8 @@ def test_linear_head():
 
 def test_adam():
     K.check_adam(None, DEV)
+    K.check_adam(None, DEV, n=5003)
+    K.check_adam(None, DEV, n=1001, offset=1)
     K.check_adam(None, DEV, n=2769120)
 
 

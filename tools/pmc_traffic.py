@@ -47,10 +47,12 @@ def main():
     gem = [r for r in rows if 'gemm' in r[0] and r[2] >= 1 and 'splitk_reduce' not in r[0]]      # (the ring kernels' signatures contain 'SplitK')
     gl = sum(r[1] for r in gem)
     lib = os.path.join(ROOT, 'aphantasia_amd', 'libaphantasia_hip.so')
+    sys.path.insert(0, ROOT)
+    from bench import gemm_src_sha          # sha256 over the ViT translation unit's sources (bench.py accepts the summary on either hash)
     out = dict(kernel_family='aph::gemm*_f16_kernel (launches occurring every step)', launches=gl,
                traffic_bytes_per_launch=sum(r[5] * 1e6 * r[1] for r in gem) / max(gl, 1),
                per_kernel_MB_per_launch={r[0][-100:]: round(r[5], 2) for r in rows},
-               lib_sha256=hashlib.sha256(open(lib, 'rb').read()).hexdigest(), workload=note,
+               lib_sha256=hashlib.sha256(open(lib, 'rb').read()).hexdigest(), gemm_src_sha256=gemm_src_sha(), workload=note,
                source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the same bench.py command; FETCH_SIZE doubled '
                       '(gfx950 half-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported')
     with open(os.path.join(ROOT, 'profiles', tag + '_pmc_hbm_traffic.json'), 'w') as f:
