@@ -21,6 +21,7 @@ constexpr int DW_IY = 16, DW_IX = 64;                  // adjoint: coefficient t
 constexpr int DC_TY = 80, DC_TX = 128, DC_NT = 1024;   // coarse-tail kernels: one tile holds a whole level (out <= 80 x 128)
 constexpr int DC_IY = 40, DC_IX = 64;                  //   adjoint: coefficient tile <= 40 x 64
 constexpr int DC_MAX_LEVELS = 12;
+constexpr int DC_HS_MAX = 12 * DC_NT;                  // detail-band values of all coarse levels together (one prefetch batch: 12 per thread)
 
 // Forward tile, separable in LDS: a TY x TX output tile of one channel by NT threads.
 //   1. the four band patches [PY][PX] (PY = TY/2 + L/2 input rows, PX likewise; zero beyond h / w) are loaded once --
@@ -260,38 +261,201 @@ __global__ __launch_bounds__(DW_NT) void idwt_level_adjoint_kernel(const float* 
                                              llh, llw, dhighs + (size_t)c * 3 * h * w, blockIdx.y * DW_IY, blockIdx.x * DW_IX);
 }
 
-// ---- coarse tail: every level whose output is one DC_TY x DC_TX tile, one workgroup per channel walking the levels --------
-// (eight such levels under a 4K db3 image were eight launches of 3 workgroups each, 6.7 us apiece of pure latency).  A level
-// reads what the previous one wrote through global memory: fence + barrier in between (the data never leaves the L2).
+// ---- coarse tail: the levels whose bands fit the LDS, one workgroup per channel walking them -----------------------------------
+// (eight such levels under a 4K db3 image were eight launches of 3 workgroups each, 6 us apiece of pure latency; a first fused
+// version that still went through global memory between levels -- load, fence, barrier -- cost 4.7 us per level, hardly less.)
+// Here nothing but the first level's low band, every level's detail bands (all requested up front: one memory round trip for the
+// whole tail) and the last level's output touches global memory: the running low band stays in LDS between levels.  Whole levels
+// need no zero padding: output pair jl reads inputs jl .. jl + L/2 - 1 <= w - 1, rows likewise.  The sums are those of idwt_tile,
+// term for term.
 struct IdwtLevel {                // forward: ll, highs -> out.  adjoint: out = incoming gradient, ll / highs = gradients written
   float* ll; float* highs; float* out;
   int llh, llw, h, w;
   float hscale;
+  int hoff;                       // forward: offset (floats) of this level's detail bands in the LDS prefetch area
 };
 struct IdwtLevels { int n; IdwtLevel lv[DC_MAX_LEVELS]; };      // in execution order
+
+constexpr int DC_LL = DC_TY * DC_TX;                  // running low band / incoming gradient, floats
+constexpr int DC_R = DC_IY * DC_TX;                   // forward: one horizontal-pass plane [h <= DC_IY][Wo <= DC_TX]
+inline size_t idwt_coarse_smem(int L, int hsum) { return sizeof(float) * (2 * L + DC_LL + 2 * DC_R + hsum); }
+inline size_t idwt_coarse_adjoint_smem(int L) { return sizeof(float) * (2 * L + DC_LL + DC_IY * DC_IX + 2 * (2 * DC_IY + L - 2) * DC_IX); }
 
 template <int H2T>
 __global__ __launch_bounds__(DC_NT) void idwt_coarse_kernel(IdwtLevels lv, const float* __restrict__ g0, const float* __restrict__ g1, int L) {
   APH_DYN_SMEM(smem);
-  const int c = blockIdx.x;
+  constexpr int H2 = H2T;
+  float* f0 = reinterpret_cast<float*>(smem);
+  float* f1 = f0 + 2 * H2;
+  float* LL = f1 + 2 * H2;             // running low band, row pitch `pitch`
+  float* rlo = LL + DC_LL;             // [h][Wo]
+  float* rhi = rlo + DC_R;
+  float* HS = rhi + DC_R;              // every level's (LH, HL, HH) x hscale
+  const int c = blockIdx.x, tid = threadIdx.x;
+  // everything the tail reads from global memory, requested before the first LDS write: the coarsest low band (<= DC_IY x DC_IX:
+  // three values per thread) and the detail bands of all levels as ONE flat index space (HS is laid out in level order, so the
+  // level of element q is the last one whose hoff <= q: a chain of selects over the level table, which sits in scalar registers)
+  constexpr int NLL = (DC_IY * DC_IX + DC_NT - 1) / DC_NT, NB = DC_HS_MAX / DC_NT;
+  float wll[NLL];
+  {
+    const IdwtLevel& l0 = lv.lv[0];
+    const int n0 = l0.llh * l0.llw;
+    const float* src = l0.ll + (size_t)c * n0;
+#pragma unroll
+    for (int u = 0; u < NLL; ++u) { const int q = u * DC_NT + tid; wll[u] = src[q < n0 ? q : 0]; }
+  }
+  const int hsum = lv.lv[lv.n - 1].hoff + 3 * lv.lv[lv.n - 1].h * lv.lv[lv.n - 1].w;      // <= DC_HS_MAX (idwt_coarse_count)
+  {
+    constexpr int base = 0;           // (one batch, not a loop: a loop header would wait for the low band's loads first)
+    float v[NB], sc[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int q = base + u * DC_NT + tid, qc = q < hsum ? q : 0;
+      const float* src = lv.lv[0].highs + (size_t)c * 3 * lv.lv[0].h * lv.lv[0].w;
+      int off = 0;
+      float s_ = lv.lv[0].hscale;
+      for (int k = 1; k < lv.n; ++k)
+        if (qc >= lv.lv[k].hoff) { src = lv.lv[k].highs + (size_t)c * 3 * lv.lv[k].h * lv.lv[k].w; off = lv.lv[k].hoff; s_ = lv.lv[k].hscale; }
+      v[u] = src[qc - off];
+      sc[u] = s_;
+    }
+    {
+      for (int k = tid; k < 2 * H2; k += DC_NT) { f0[k] = g0[k]; f1[k] = g1[k]; }
+      const int n0 = lv.lv[0].llh * lv.lv[0].llw;
+#pragma unroll
+      for (int u = 0; u < NLL; ++u) { const int q = u * DC_NT + tid; if (q < n0) LL[q] = wll[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int q = base + u * DC_NT + tid;
+      if (q < hsum) HS[q] = v[u] * sc[u];
+    }
+  }
+  __syncthreads();
+  int pitch = lv.lv[0].llw;
   for (int i = 0; i < lv.n; ++i) {
     const IdwtLevel& l = lv.lv[i];
-    const int Ho = 2 * l.h - L + 2, Wo = 2 * l.w - L + 2;
-    if (i) { __threadfence(); __syncthreads(); }
-    idwt_tile<H2T, DC_TY, DC_TX, DC_NT>(smem, l.ll + (size_t)c * l.llh * l.llw, l.llw, l.highs + (size_t)c * 3 * l.h * l.w, l.h, l.w, g0, g1, L,
-                                        l.hscale, l.out + (size_t)c * Ho * Wo, Ho, Wo, 0, 0);
+    const int h = l.h, w = l.w, Ho = 2 * h - L + 2, Wo = 2 * w - L + 2, W2 = Wo >> 1;
+    const float* Hlh = HS + l.hoff;
+    const float* Hhl = Hlh + h * w;
+    const float* Hhh = Hhl + h * w;
+    for (int q = tid; q < h * W2; q += DC_NT) {
+      const int py = q / W2, jl = q - py * W2;
+      const int e0 = jl + H2 - 1;
+      const float* rll = LL + py * pitch;
+      const float* rlh = Hlh + py * w;
+      const float* rhl = Hhl + py * w;
+      const float* rhh = Hhh + py * w;
+      float lo_e = 0.f, lo_o = 0.f, hi_e = 0.f, hi_o = 0.f;
+#pragma unroll
+      for (int t = 0; t < H2; ++t) {
+        const float a_e = f0[2 * t], a_o = f0[2 * t + 1], b_e = f1[2 * t], b_o = f1[2 * t + 1];
+        const float vll = rll[e0 - t], vlh = rlh[e0 - t], vhl = rhl[e0 - t], vhh = rhh[e0 - t];
+        lo_e += a_e * vll + b_e * vhl; lo_o += a_o * vll + b_o * vhl;
+        hi_e += a_e * vlh + b_e * vhh; hi_o += a_o * vlh + b_o * vhh;
+      }
+      *reinterpret_cast<float2*>(rlo + py * Wo + 2 * jl) = make_float2(lo_e, lo_o);      // (8-byte aligned: Wo is even)
+      *reinterpret_cast<float2*>(rhi + py * Wo + 2 * jl) = make_float2(hi_e, hi_o);
+    }
+    __syncthreads();
+    // vertical pass: the level's output is the next level's low band (row pitch Wo); only the last one leaves the CU
+    const bool last = i + 1 == lv.n;
+    float* gout = l.out + (size_t)c * Ho * Wo;
+    for (int q = tid; q < (Ho >> 1) * Wo; q += DC_NT) {
+      const int rl = q / Wo, x = q - rl * Wo;
+      const int e0 = (rl + H2 - 1) * Wo + x;
+      float o_e = 0.f, o_o = 0.f;
+#pragma unroll
+      for (int t = 0; t < H2; ++t) {
+        const float lo = rlo[e0 - t * Wo], hi = rhi[e0 - t * Wo];
+        o_e += f0[2 * t] * lo + f1[2 * t] * hi;
+        o_o += f0[2 * t + 1] * lo + f1[2 * t + 1] * hi;
+      }
+      LL[2 * rl * Wo + x] = o_e;
+      LL[(2 * rl + 1) * Wo + x] = o_o;
+      if (last) { gout[(size_t)2 * rl * Wo + x] = o_e; gout[(size_t)(2 * rl + 1) * Wo + x] = o_o; }
+    }
+    __syncthreads();
+    pitch = Wo;
   }
 }
+
+// adjoint of the coarse tail, finest of its levels first: the incoming gradient is read from global memory once, each level's
+// low-band gradient stays in LDS as the next level's input, the detail-band gradients (and the coarsest low band's) are stored.
 template <int LT>
-__global__ __launch_bounds__(DC_NT) void idwt_coarse_adjoint_kernel(IdwtLevels lv, const float* __restrict__ g0, const float* __restrict__ g1, int L) {
+__global__ __launch_bounds__(DC_NT) void idwt_coarse_adjoint_kernel(IdwtLevels lv, const float* __restrict__ g0, const float* __restrict__ g1, int L_) {
   APH_DYN_SMEM(smem);
-  const int c = blockIdx.x;
+  constexpr int L = LT;
+  float* f0 = reinterpret_cast<float*>(smem);
+  float* f1 = f0 + L;
+  float* DA = f1 + L;                  // the level's incoming gradient [Ho][Wo]
+  float* DB = DA + DC_LL;              // its low-band gradient [llh][llw] = the next level's incoming gradient (the two swap)
+  float* slo = DB + DC_IY * DC_IX;     // [PY = 2 llh + L - 2][llw]
+  float* shi = slo + (2 * DC_IY + L - 2) * DC_IX;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  {
+    // the tail's only read from global memory: the first level's incoming gradient (<= DC_TY x DC_TX), all loads in flight together
+    constexpr int NA = (DC_LL + DC_NT - 1) / DC_NT;
+    const IdwtLevel& l0 = lv.lv[0];
+    const int n0 = (2 * l0.h - L + 2) * (2 * l0.w - L + 2);
+    const float* src = l0.out + (size_t)c * n0;
+    float v[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int q = u * DC_NT + tid; v[u] = src[q < n0 ? q : 0]; }
+    for (int k = tid; k < L; k += DC_NT) { f0[k] = g0[k]; f1[k] = g1[k]; }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int q = u * DC_NT + tid; if (q < n0) DA[q] = v[u]; }
+  }
+  __syncthreads();
   for (int i = 0; i < lv.n; ++i) {
     const IdwtLevel& l = lv.lv[i];
-    const int Ho = 2 * l.h - L + 2, Wo = 2 * l.w - L + 2;
-    if (i) { __threadfence(); __syncthreads(); }
-    idwt_adjoint_tile<LT, DC_IY, DC_IX, DC_NT>(smem, l.out + (size_t)c * Ho * Wo, Ho, Wo, l.h, l.w, g0, g1, L, l.hscale,
-                                               l.ll + (size_t)c * l.llh * l.llw, l.llh, l.llw, l.highs + (size_t)c * 3 * l.h * l.w, 0, 0);
+    const int h = l.h, w = l.w, llh = l.llh, llw = l.llw, Ho = 2 * h - L + 2, Wo = 2 * w - L + 2;
+    const int PY = 2 * llh + L - 2;
+    for (int q = tid; q < PY * llw; q += DC_NT) {
+      const int py = q / llw, ixl = q - py * llw;
+      const int my = py - (L - 2), mxb = 2 * ixl - (L - 2);
+      const bool rowok = my >= 0 && my < Ho;
+      const float* row = DA + (rowok ? my : 0) * Wo;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int t = 0; t < L / 2; ++t) {
+        const int mx = mxb + 2 * t;
+        const float vx = (rowok && mx >= 0 && mx < Wo) ? row[mx] : 0.f;
+        const float vy = (rowok && mx + 1 >= 0 && mx + 1 < Wo) ? row[mx + 1] : 0.f;
+        a += f0[2 * t] * vx; a += f0[2 * t + 1] * vy;
+        b += f1[2 * t] * vx; b += f1[2 * t + 1] * vy;
+      }
+      slo[q] = a;
+      shi[q] = b;
+    }
+    __syncthreads();
+    const bool last = i + 1 == lv.n;
+    float* gll = l.ll + (size_t)c * llh * llw;
+    float* gh = l.highs + (size_t)c * 3 * h * w;
+    for (int q = tid; q < llh * llw; q += DC_NT) {
+      const int iyl = q / llw, ixl = q - iyl * llw;
+      if (iyl >= h || ixl >= w) {       // the row / column DWTInverse drops
+        DB[q] = 0.f;
+        if (last) gll[q] = 0.f;
+        continue;
+      }
+      float all = 0.f, alh = 0.f, ahl = 0.f, ahh = 0.f;
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        const int e = (2 * iyl + k) * llw + ixl;
+        const float lo = slo[e], hi = shi[e];
+        all += f0[k] * lo; alh += f1[k] * lo;
+        ahl += f0[k] * hi; ahh += f1[k] * hi;
+      }
+      DB[q] = all;
+      if (last) gll[q] = all;
+      float* oh = gh + (size_t)iyl * w + ixl;
+      oh[0] = alh * l.hscale;
+      oh[(size_t)h * w] = ahl * l.hscale;
+      oh[2 * (size_t)h * w] = ahh * l.hscale;
+    }
+    __syncthreads();
+    float* t_ = DA; DA = DB; DB = t_;
   }
 }
 
@@ -319,9 +483,9 @@ void launch_idwt_coarse_adjoint(const IdwtLevels& lv, int C, size_t smem, hipStr
   APH_LAUNCH(idwt_coarse_adjoint_kernel<LT>, dim3(C), dim3(DC_NT), smem, st, lv, d_g0, d_g1, L);
 }
 
-// filter lengths the coarse-tail kernels are built for (fully unrolled loops; their LDS patch and their registers grow with L:
-// at L = 12 the 1024-thread forward kernel would spill)
+// filter lengths the coarse-tail kernels are instantiated for (fully unrolled filter loops)
 inline bool idwt_coarse_length(int L) { return L == 2 || L == 4 || L == 6 || L == 8; }
+constexpr size_t kCoarseSmemMax = 150 * 1024;
 // APH_IDWT_COARSE=0: one launch per level throughout (A/B runs)
 inline bool idwt_coarse_enabled() {
   static const bool on = [] { const char* e = getenv("APH_IDWT_COARSE"); return !(e && e[0] == '0'); }();
@@ -361,7 +525,8 @@ void idwt_level_bwd(const float* d_out_grad, int h, int w, int C, const float* d
 #undef APH_IDWT_BWD
 }
 void idwt_coarse_fwd(const IdwtLevels& lv, int C, const float* d_g0, const float* d_g1, int L, hipStream_t st) {
-  const size_t smem = idwt_tile_smem<DC_TY, DC_TX>(L);
+  const IdwtLevel& lastl = lv.lv[lv.n - 1];
+  const size_t smem = idwt_coarse_smem(L, lastl.hoff + 3 * lastl.h * lastl.w);
   switch (L) {
     case 2: launch_idwt_coarse<1>(lv, C, smem, st, d_g0, d_g1, L); break;
     case 4: launch_idwt_coarse<2>(lv, C, smem, st, d_g0, d_g1, L); break;
@@ -370,7 +535,7 @@ void idwt_coarse_fwd(const IdwtLevels& lv, int C, const float* d_g0, const float
   }
 }
 void idwt_coarse_bwd(const IdwtLevels& lv, int C, const float* d_g0, const float* d_g1, int L, hipStream_t st) {
-  const size_t smem = idwt_adjoint_tile_smem<DC_IY, DC_IX>(L);
+  const size_t smem = idwt_coarse_adjoint_smem(L);
   switch (L) {
     case 2: launch_idwt_coarse_adjoint<2>(lv, C, smem, st, d_g0, d_g1, L); break;
     case 4: launch_idwt_coarse_adjoint<4>(lv, C, smem, st, d_g0, d_g1, L); break;
@@ -397,11 +562,13 @@ int idwt_check_levels(const char* who, const int* hs, const int* ws, int J, int 
 // number of levels, counted from the coarsest, that the coarse-tail kernel takes (0: none -- it needs at least two to pay)
 inline int idwt_coarse_count(const int* hs, const int* ws, int J, int L) {
   if (!idwt_coarse_enabled() || !idwt_coarse_length(L)) return 0;
-  int n = 0;
+  int n = 0, hsum = 0;
   for (int j = J - 1; j >= 0 && n < DC_MAX_LEVELS; --j, ++n) {
     int llh, llw;
     idwt_ll_size(hs, ws, J, L, j, &llh, &llw);
     if (2 * hs[j] - L + 2 > DC_TY || 2 * ws[j] - L + 2 > DC_TX || llh > DC_IY || llw > DC_IX) break;
+    hsum += 3 * hs[j] * ws[j];
+    if (hsum > DC_HS_MAX || idwt_coarse_smem(L, hsum) > kCoarseSmemMax) break;      // (the detail bands of all its levels: one prefetch batch, and they must fit the LDS)
   }
   return n >= 2 ? n : 0;
 }
@@ -438,7 +605,8 @@ int aph_idwt_level_bwd(const float* d_out_grad, int h, int w, int C, const float
 
 // Every level of DWTInverse in one call (image.py:36-38,67).  Host arrays of J entries, level 0 = finest: hs / ws = size of
 // the level's detail bands, hscales = dwt_scale gains, d_highs[j] [C,3,hs[j],ws[j]] (device), d_bufs[j] [C, 2 hs[j]-L+2,
-// 2 ws[j]-L+2] = the running low band after level j (caller-owned; d_bufs[0] is the image).  d_yl [C, hs[J-1], ws[J-1]].
+// 2 ws[j]-L+2] = scratch for the running low band after level j (caller-owned; d_bufs[0] receives the image, the others are
+// only written where a level's output has to travel through global memory).  d_yl [C, hs[J-1], ws[J-1]].
 int aph_idwt_fwd(const float* d_yl, const float* const* d_highs, const int* hs, const int* ws, const float* hscales, int J, int C,
                  const float* d_g0, const float* d_g1, int L, float* const* d_bufs, void* stream_) {
   APH_TRY
@@ -452,10 +620,12 @@ int aph_idwt_fwd(const float* d_yl, const float* const* d_highs, const int* hs, 
   if (nc) {
     IdwtLevels lv;
     lv.n = nc;
+    int hoff = 0;
     for (int i = 0; i < nc; ++i, --j) {
       int llh, llw;
       idwt_ll_size(hs, ws, J, L, j, &llh, &llw);
-      lv.lv[i] = IdwtLevel{const_cast<float*>(j + 1 < J ? d_bufs[j + 1] : d_yl), const_cast<float*>(d_highs[j]), d_bufs[j], llh, llw, hs[j], ws[j], hscales[j]};
+      lv.lv[i] = IdwtLevel{const_cast<float*>(j + 1 < J ? d_bufs[j + 1] : d_yl), const_cast<float*>(d_highs[j]), d_bufs[j], llh, llw, hs[j], ws[j], hscales[j], hoff};
+      hoff += 3 * hs[j] * ws[j];
     }
     idwt_coarse_fwd(lv, C, d_g0, d_g1, L, st);
   }
@@ -493,7 +663,7 @@ int aph_idwt_bwd(const float* d_img_grad, const int* hs, const int* ws, const fl
       int llh, llw;
       idwt_ll_size(hs, ws, J, L, j, &llh, &llw);
       lv.lv[i] = IdwtLevel{j + 1 < J ? d_gbufs[j + 1] : d_yl_grad, d_highs_grad[j], const_cast<float*>(j ? d_gbufs[j] : d_img_grad), llh, llw, hs[j], ws[j],
-                           hscales[j]};
+                           hscales[j], 0};
     }
     idwt_coarse_bwd(lv, C, d_g0, d_g1, L, st);
   }

@@ -90,9 +90,10 @@ int aph_idwt_level_bwd(const float* d_out_grad, int h, int w, int C, const float
 
 /* Every level of DWTInverse in one call (what dwt_image.inner runs per step, image.py:36-38,67).  Host arrays of J entries,
  * level 0 = finest: hs / ws = size of the level's detail bands, hscales = dwt_scale gains (image.py:73-80), d_highs[j]
- * [C,3,hs[j],ws[j]] (device pointers), d_bufs[j] [C, 2 hs[j]-L+2, 2 ws[j]-L+2] = the running low band after level j
- * (caller-owned scratch; d_bufs[0] receives the image).  d_yl [C, hs[J-1], ws[J-1]] = the coarsest low band.
- * The levels whose output is a single tile run in one launch (APH_IDWT_COARSE=0: one launch per level). */
+ * [C,3,hs[j],ws[j]] (device pointers), d_bufs[j] [C, 2 hs[j]-L+2, 2 ws[j]-L+2] = caller-owned scratch for the running low band
+ * after level j (d_bufs[0] receives the image; the others are written only where a level's output travels through global
+ * memory).  d_yl [C, hs[J-1], ws[J-1]] = the coarsest low band.  The coarse levels -- output up to 80 x 128 -- run in one launch
+ * with the running low band kept in LDS (filter lengths 2-8; APH_IDWT_COARSE=0: one launch per level throughout). */
 int aph_idwt_fwd(const float* d_yl, const float* const* d_highs, const int* hs, const int* ws, const float* hscales, int J,
                  int C, const float* d_g0, const float* d_g1, int L, float* const* d_bufs, void* stream);
 /* adjoint: d_img_grad [C, 2 hs[0]-L+2, 2 ws[0]-L+2] -> d_highs_grad[j] [C,3,hs[j],ws[j]] and d_yl_grad [C,hs[J-1],ws[J-1]];

@@ -463,7 +463,12 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2):
         gp0 = vit.backward((genc * LS).to(dev).contiguous(), S, out_scale=1.0 / LS).clone()
     finally:
         L.call('aph_vit_set_fuse_ln', prev)
-    assert torch.equal(enc0, enc1) and torch.equal(gp0, gp1)
+    if dev == 'cpu':
+        assert torch.equal(enc0, enc1) and torch.equal(gp0, gp1)
+    else:       # (on the GPU the two instantiations may round their multiply-adds differently: tools/exp/ln_fuse_diff.py prints by how much)
+        de, dg = (enc0 - enc1).abs().max().item(), (gp0.float() - gp1.float()).abs().max().item()
+        print('fused vs separate LayerNorm pairs: max |d enc| %.2e, max |d grad| %.2e' % (de, dg))
+        assert de <= fwd_tol * enc1.abs().max().item() and dg <= bwd_tol * gp1.float().abs().max().item(), (de, dg)
     return ferr, berr
 
 
