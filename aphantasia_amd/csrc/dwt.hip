@@ -273,6 +273,7 @@ struct IdwtLevel {                // forward: ll, highs -> out.  adjoint: out = 
   int llh, llw, h, w;
   float hscale;
   int hoff;                       // forward: offset (floats) of this level's detail bands in the LDS prefetch area
+  int hdelta;                     // forward: highs - (the first level's highs), in floats (the host checks that it fits)
 };
 struct IdwtLevels { int n; IdwtLevel lv[DC_MAX_LEVELS]; };      // in execution order
 
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(DC_NT) void idwt_coarse_kernel(IdwtLevels lv, const
   float* LL = f1 + 2 * H2;             // running low band, row pitch `pitch`
   float* rlo = LL + DC_LL;             // [h][Wo]
   float* rhi = rlo + DC_R;
-  float* HS = rhi + DC_R;              // every level's (LH, HL, HH) x hscale
+  float* HS = rhi + DC_R;              // every level's (LH, HL, HH)
   const int c = blockIdx.x, tid = threadIdx.x;
   // everything the tail reads from global memory, requested before the first LDS write: the coarsest low band (<= DC_IY x DC_IX:
   // three values per thread) and the detail bands of all levels as ONE flat index space (HS is laid out in level order, so the
@@ -306,29 +307,35 @@ __global__ __launch_bounds__(DC_NT) void idwt_coarse_kernel(IdwtLevels lv, const
   }
   const int hsum = lv.lv[lv.n - 1].hoff + 3 * lv.lv[lv.n - 1].h * lv.lv[lv.n - 1].w;      // <= DC_HS_MAX (idwt_coarse_count)
   {
-    constexpr int base = 0;           // (one batch, not a loop: a loop header would wait for the low band's loads first)
-    float v[NB], sc[NB];
+    // element q of HS belongs to the last level whose hoff <= q; its address is (first level's highs) + q + d_k with
+    // d_k = hdelta_k + c * 3 h_k w_k - hoff_k.  The level table is read at compile-time indices (scalar registers, loaded once):
+    // per element one compare + select per level.  (A run-time loop over the table cost a dependent scalar load per level and
+    // element: 10 us of the kernel's 22.)
+    const float* h0 = lv.lv[0].highs;
+    int dk[DC_MAX_LEVELS], ho[DC_MAX_LEVELS];       // (wave-uniform: scalar registers; an unused slot never matches)
+#pragma unroll
+    for (int k = 0; k < DC_MAX_LEVELS; ++k) {
+      const bool on = k < lv.n;
+      ho[k] = on ? lv.lv[k].hoff : 0x7fffffff;
+      dk[k] = on ? lv.lv[k].hdelta + c * 3 * lv.lv[k].h * lv.lv[k].w - lv.lv[k].hoff : 0;
+    }
+    float v[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int q = base + u * DC_NT + tid, qc = q < hsum ? q : 0;
-      const float* src = lv.lv[0].highs + (size_t)c * 3 * lv.lv[0].h * lv.lv[0].w;
-      int off = 0;
-      float s_ = lv.lv[0].hscale;
-      for (int k = 1; k < lv.n; ++k)
-        if (qc >= lv.lv[k].hoff) { src = lv.lv[k].highs + (size_t)c * 3 * lv.lv[k].h * lv.lv[k].w; off = lv.lv[k].hoff; s_ = lv.lv[k].hscale; }
-      v[u] = src[qc - off];
-      sc[u] = s_;
-    }
-    {
-      for (int k = tid; k < 2 * H2; k += DC_NT) { f0[k] = g0[k]; f1[k] = g1[k]; }
-      const int n0 = lv.lv[0].llh * lv.lv[0].llw;
+      const int q = u * DC_NT + tid, qc = q < hsum ? q : 0;
+      int d = dk[0];
 #pragma unroll
-      for (int u = 0; u < NLL; ++u) { const int q = u * DC_NT + tid; if (q < n0) LL[q] = wll[u]; }
+      for (int k = 1; k < DC_MAX_LEVELS; ++k) d = qc >= ho[k] ? dk[k] : d;
+      v[u] = h0[(ptrdiff_t)d + qc];
     }
+    for (int k = tid; k < 2 * H2; k += DC_NT) { f0[k] = g0[k]; f1[k] = g1[k]; }
+    const int n0 = lv.lv[0].llh * lv.lv[0].llw;
+#pragma unroll
+    for (int u = 0; u < NLL; ++u) { const int q = u * DC_NT + tid; if (q < n0) LL[q] = wll[u]; }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int q = base + u * DC_NT + tid;
-      if (q < hsum) HS[q] = v[u] * sc[u];
+      const int q = u * DC_NT + tid;
+      if (q < hsum) HS[q] = v[u];       // (unscaled: the level's gain is applied where the value is used)
     }
   }
   __syncthreads();
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(DC_NT) void idwt_coarse_kernel(IdwtLevels lv, const
   for (int i = 0; i < lv.n; ++i) {
     const IdwtLevel& l = lv.lv[i];
     const int h = l.h, w = l.w, Ho = 2 * h - L + 2, Wo = 2 * w - L + 2, W2 = Wo >> 1;
+    const float hsc = l.hscale;
     const float* Hlh = HS + l.hoff;
     const float* Hhl = Hlh + h * w;
     const float* Hhh = Hhl + h * w;
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(DC_NT) void idwt_coarse_kernel(IdwtLevels lv, const
 #pragma unroll
       for (int t = 0; t < H2; ++t) {
         const float a_e = f0[2 * t], a_o = f0[2 * t + 1], b_e = f1[2 * t], b_o = f1[2 * t + 1];
-        const float vll = rll[e0 - t], vlh = rlh[e0 - t], vhl = rhl[e0 - t], vhh = rhh[e0 - t];
+        const float vll = rll[e0 - t], vlh = rlh[e0 - t] * hsc, vhl = rhl[e0 - t] * hsc, vhh = rhh[e0 - t] * hsc;
         lo_e += a_e * vll + b_e * vhl; lo_o += a_o * vll + b_o * vhl;
         hi_e += a_e * vlh + b_e * vhh; hi_o += a_o * vlh + b_o * vhh;
       }
@@ -621,13 +629,18 @@ int aph_idwt_fwd(const float* d_yl, const float* const* d_highs, const int* hs, 
     IdwtLevels lv;
     lv.n = nc;
     int hoff = 0;
+    bool fits = true;
     for (int i = 0; i < nc; ++i, --j) {
       int llh, llw;
       idwt_ll_size(hs, ws, J, L, j, &llh, &llw);
-      lv.lv[i] = IdwtLevel{const_cast<float*>(j + 1 < J ? d_bufs[j + 1] : d_yl), const_cast<float*>(d_highs[j]), d_bufs[j], llh, llw, hs[j], ws[j], hscales[j], hoff};
+      const ptrdiff_t delta = d_highs[j] - d_highs[J - 1];      // (in floats; the kernel addresses every level's bands from the first one's pointer)
+      if (delta > (ptrdiff_t)0x3fffffff || delta < -(ptrdiff_t)0x3fffffff) { fits = false; break; }
+      lv.lv[i] = IdwtLevel{const_cast<float*>(j + 1 < J ? d_bufs[j + 1] : d_yl), const_cast<float*>(d_highs[j]), d_bufs[j], llh, llw, hs[j], ws[j], hscales[j], hoff,
+                           (int)delta};
       hoff += 3 * hs[j] * ws[j];
     }
-    idwt_coarse_fwd(lv, C, d_g0, d_g1, L, st);
+    if (fits) idwt_coarse_fwd(lv, C, d_g0, d_g1, L, st);
+    else j = J - 1;                      // (detail bands in allocations too far apart for 32-bit offsets: one launch per level)
   }
   for (; j >= 0; --j) {
     int llh, llw;
@@ -663,7 +676,7 @@ int aph_idwt_bwd(const float* d_img_grad, const int* hs, const int* ws, const fl
       int llh, llw;
       idwt_ll_size(hs, ws, J, L, j, &llh, &llw);
       lv.lv[i] = IdwtLevel{j + 1 < J ? d_gbufs[j + 1] : d_yl_grad, d_highs_grad[j], const_cast<float*>(j ? d_gbufs[j] : d_img_grad), llh, llw, hs[j], ws[j],
-                           hscales[j], 0};
+                           hscales[j], 0, 0};
     }
     idwt_coarse_bwd(lv, C, d_g0, d_g1, L, st);
   }
