@@ -229,3 +229,32 @@ def test_rccl_unique_id_exchange_two_processes(mode):
     for p in procs:
         p.join(60)
     assert res[0] == bytes(range(128)) and res[1] == bytes(range(128))
+
+
+def test_bench_traffic_summary_matching(tmp_path, monkeypatch):
+    """bench.py quotes `roofline.traffic` from a committed PMC summary only when that summary was taken on the library being timed or on
+    byte-identical GEMM sources; otherwise it is flagged stale.  The newest matching file wins, file order is by name (not mtime)."""
+    import json
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'lib_sha', lambda: 'L' * 64)
+    monkeypatch.setattr(bench, 'gemm_src_sha', lambda: 'G' * 64)
+
+    def write(name, **kw):
+        (prof / name).write_text(json.dumps(dict(traffic_bytes_per_launch=float(len(name)), **kw)))
+    assert bench.pmc_traffic('r*_pmc_hbm_traffic*.json') == (None, None, None, None)
+    write('r01_pmc_hbm_traffic.json', lib_sha256='x')
+    assert bench.pmc_traffic('r*_pmc_hbm_traffic*.json')[2:] == (True, None)                 # nothing matches: the newest one, flagged stale
+    write('r02_pmc_hbm_traffic.json', lib_sha256='y', gemm_src_sha256='G' * 64)
+    write('r03_pmc_hbm_traffic.json', lib_sha256='z')
+    t, src, stale, match = bench.pmc_traffic('r*_pmc_hbm_traffic*.json')
+    assert (os.path.basename(src), stale, match) == ('r02_pmc_hbm_traffic.json', False, 'gemm_sources')
+    write('r04_pmc_hbm_traffic.json', lib_sha256='L' * 64)
+    t, src, stale, match = bench.pmc_traffic('r*_pmc_hbm_traffic*.json')
+    assert (os.path.basename(src), stale, match) == ('r04_pmc_hbm_traffic.json', False, 'library')
+    # the committed round-3 summary matches this checkout's GEMM sources (the GEMM kernels have not changed since it was taken)
+    monkeypatch.undo()
+    real = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')))
+    assert real['gemm_src_sha256'] == bench.gemm_src_sha()
