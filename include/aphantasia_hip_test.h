@@ -28,6 +28,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
  *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
+ *   13  64x64, 4 waves, 8-stage ring (seven k-tiles in flight per CU: the small-M experiment of vit_gemm_deep.h; not yet measured on hardware)
  *   22 / 24  128x128 split-K x2 / x4
  * | 0x100 (with 2, 4 or 5 only): measurement variant whose epilogue keeps the accumulators live but never stores (upper bound of
  *   what overlapping the store phase could gain: tools/exp/gemm_nostore.py).

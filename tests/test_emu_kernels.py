@@ -36,6 +36,9 @@ def test_dwt(emu):
     K.check_dwt(emu, 'cpu', 'db3', 48, 72)          # rows of 4 outputs per lane (16-byte stores) in the finest level
     K.check_dwt(emu, 'cpu', 'db2', 40, 56)
     K.check_dwt(emu, 'cpu', 'db5', 50, 60)          # run-time filter length: the generic row-loop loads
+    K.check_dwt(emu, 'cpu', 'haar', 40, 56)         # the L = 2 and L = 8 instantiations of the coarse-tail kernels
+    K.check_dwt(emu, 'cpu', 'db4', 64, 80)
+    K.check_dwt(emu, 'cpu', 'db3', 200, 300)        # two per-level launches (several tiles each), then the coarse tail
 
 
 def test_fft_pair(emu):
@@ -99,6 +102,7 @@ def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(70, 128, 192)], tile_cfg=8)
     K.check_gemm(emu, 'cpu', [(200, 256, 320)], tile_cfg=10)   # 128x128, 8 waves, 4-stage ring
     K.check_gemm(emu, 'cpu', [(70, 128, 64)], tile_cfg=2)     # single k-tile, single partial tile
+    K.check_gemm(emu, 'cpu', [(150, 128, 768), (64, 128, 128), (70, 128, 64), (130, 256, 448)], tile_cfg=13, variants=(0,))   # 64x64, 8-stage ring (experiment, vit_gemm_deep.h): 12 / 2 / 1 / 7 k-tiles
     # wave-specialised persistent kernel (vit_gemm_ws.h): producer / consumer waves, permuted Bt rows, register epilogue;
     # single unit, ragged single tile, 9 / 10 tiles on 3 workgroups with odd and even k-tile counts
     K.check_gemm(emu, 'cpu', [(70, 128, 64), (300, 256, 192), (700, 768, 192), (1100, 512, 128)], tile_cfg=5, variants=(0,))

@@ -1,9 +1,11 @@
 """GPU (MI355X): every kernel of libaphantasia_hip.so through the C ABI against the oracle and the
 reference-generated goldens, at the golden sizes and at BASELINE.json's full sizes."""
+import os
+
 import pytest
 import torch
 
-from aphantasia_amd import _ffi
+from aphantasia_amd import _ffi, ops
 import kernel_checks as K
 
 pytestmark = pytest.mark.gpu
@@ -164,6 +166,21 @@ def test_gemm_every_tile_config():
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
     K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64)], tile_cfg=11, variants=(0,))       # two workgroups per CU (2-stage ring)
     K.check_gemm(None, DEV, [(9500, 3072, 768), (18715, 3072, 768)], tile_cfg=4, variants=(0,))   # persistent loop: 456 / 888 tiles on 256 CUs
+
+
+@pytest.mark.skipif(os.environ.get('APH_TEST_EXPERIMENTS') != '1', reason='tile_cfg 13 (8-stage ring, vit_gemm_deep.h) has not run on hardware yet: '
+                    'APH_TEST_EXPERIMENTS=1 enables its first GPU check (the counted vmcnt waits are what the interpreter cannot see)')
+def test_gemm_deep_ring_experiment_vs_matmul_and_reproducible():
+    K.check_gemm(None, DEV, [(1200, 768, 768), (1200, 768, 3072), (1200, 2304, 768), (333, 256, 64), (64, 128, 128)], tile_cfg=13, variants=(0,))
+    A = torch.randn(1200, 3072, device=DEV).half()
+    B = torch.randn(768, 3072, device=DEV).half()
+    outs = []
+    for _ in range(20):
+        C = torch.empty(1200, 768, device=DEV)
+        _ffi.lib().call('aph_gemm_f16_ld', ops.ptr(A), 3072, ops.ptr(B), 3072, 1200, 768, 3072, ops.ptr(C), 13, ops._stream(C))
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])      # an under-waited DMA shows up as run-to-run differences
 
 
 def test_gemm_wave_specialised_vs_matmul_and_reproducible():
