@@ -172,6 +172,36 @@ def mfma_peak(lib, dev):
     return res
 
 
+def irdwt_roofline(eng):
+    """the HBM-bound part of C4: inverse DWT forward + adjoint of a DWT-parameterised engine, timed with events on the (current) launch
+    stream; algorithmic bytes = every level's inputs read once + its output written once"""
+    syn = eng.dwt
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    graw = torch.randn_like(eng.raw)
+    reps = 20
+    for _ in range(2):
+        syn.forward(eng.params)
+        syn.backward(graw, eng.grad)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        syn.forward(eng.params)
+    e1.record()
+    for _ in range(reps):
+        syn.backward(graw, eng.grad)
+    e2.record()
+    torch.cuda.synchronize()
+    elems = 0
+    for (hh, ww), (ho, wo) in zip(syn.sizes, syn.out_sizes):
+        elems += 3 * (4 * hh * ww + ho * wo)              # read ll + 3 detail bands, write the level's output
+    by = 4.0 * elems
+    tf, tb = e0.elapsed_time(e1) / reps * 1e-3, e1.elapsed_time(e2) / reps * 1e-3
+    return dict(bound='hbm', kernel='aph::idwt_level_kernel + idwt_coarse_kernel / their adjoints (all levels, one aph_idwt_fwd / aph_idwt_bwd call each)', unit='GB/s',
+                peak=HBM_ACHIEVABLE_GBS, algorithmic_bytes_per_pass=by, fwd_us=tf * 1e6, bwd_us=tb * 1e6,
+                achieved=by / tf / 1e9, frac=by / tf / 1e9 / HBM_ACHIEVABLE_GBS,
+                achieved_adjoint=by / tb / 1e9, frac_adjoint=by / tb / 1e9 / HBM_ACHIEVABLE_GBS)
+
+
 def lib_sha():
     from aphantasia_amd import _ffi
     with open(_ffi.LIB_PATH, 'rb') as f:
@@ -387,30 +417,7 @@ def main():
                         step_frac_note='algorithmic_tflop_per_step x steps/s / peak (whole step, every kernel and gap included)',
                         peak_measured=mfma_peak(lib, dev))
         if cfg.get('dwt'):
-            # the HBM-bound part of C4: inverse DWT forward + adjoint, timed with events on the (current) launch stream
-            syn = eng.dwt
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            graw = torch.randn_like(eng.raw)
-            reps = 20
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                syn.forward(eng.params)
-            e1.record()
-            for _ in range(reps):
-                syn.backward(graw, eng.grad)
-            e2.record()
-            torch.cuda.synchronize()
-            elems = 0
-            for (hh, ww), (ho, wo) in zip(syn.sizes, syn.out_sizes):
-                elems += 3 * (4 * hh * ww + ho * wo)              # read ll + 3 detail bands, write the level's output
-            by = 4.0 * elems
-            tf, tb = e0.elapsed_time(e1) / reps * 1e-3, e1.elapsed_time(e2) / reps * 1e-3
-            roof_dwt = dict(bound='hbm', kernel='aph::idwt_level_kernel + idwt_coarse_kernel / their adjoints (all levels, one aph_idwt_fwd / aph_idwt_bwd call each)', unit='GB/s',
-                            peak=HBM_ACHIEVABLE_GBS, algorithmic_bytes_per_pass=by, fwd_us=tf * 1e6, bwd_us=tb * 1e6,
-                            achieved=by / tf / 1e9, frac=by / tf / 1e9 / HBM_ACHIEVABLE_GBS,
-                            achieved_adjoint=by / tb / 1e9, frac_adjoint=by / tb / 1e9 / HBM_ACHIEVABLE_GBS)
-            roof = dict(roof or {}, irdwt=roof_dwt)
+            roof = dict(roof or {}, irdwt=irdwt_roofline(eng))
 
     legs = None
     if world == 1 and not a.no_legs and a.config in ('c2', 'c3', 'c4') and cfg['transform'] == 'fast' and not cfg.get('illustrip'):
@@ -467,6 +474,10 @@ def main():
             dt4 = timed(e4, None, n4, 3)
             legs['c4'] = dict(value=n4 / dt4, unit='steps/s', ms_per_step=1e3 * dt4 / n4, steps=n4, samples_effective=S4, skipped_steps=int(e4.guard[0]),
                               note='BASELINE configs[3]: 3840x2160 DWT db3, ViT-B/16, --samples 400 -> %d cuts (full line: --config c4)' % S4)
+            try:                     # its HBM-bound part against the achievable bandwidth (roofline.irdwt of the --config c4 line)
+                legs['c4']['irdwt'] = irdwt_roofline(e4)
+            except Exception as e:
+                legs['c4']['irdwt'] = dict(error=repr(e))
             del e4, m4
         except Exception as e:       # the C4 leg must never take the headline down with it
             legs['c4'] = dict(error=repr(e))
