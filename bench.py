@@ -202,6 +202,26 @@ def irdwt_roofline(eng):
                 achieved_adjoint=by / tb / 1e9, frac_adjoint=by / tb / 1e9 / HBM_ACHIEVABLE_GBS)
 
 
+def other_config_legs(names, steps=30, timeout_s=90):
+    """`python bench.py --config <name>` (no legs, no CPU baseline, no roofline pass) in a child process per configuration -> its value line, abridged"""
+    import subprocess
+    out = {}
+    for name in names:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(steps), '--warmup', '5', '--no-cpu-baseline', '--no-legs',
+                                '--no-roofline'], capture_output=True, text=True, timeout=timeout_s)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not lines:
+                out[name] = dict(error='exit code %d: %s' % (r.returncode, r.stderr.strip()[-300:]))
+                continue
+            d = json.loads(lines[-1])
+            out[name] = dict(value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], workload=d['config'].get('workload'),
+                             samples_effective=d['config'].get('samples_effective'), skipped_steps=d['config'].get('skipped_steps'))
+        except Exception as e:
+            out[name] = dict(error=repr(e))
+    return out
+
+
 def lib_sha():
     from aphantasia_amd import _ffi
     with open(_ffi.LIB_PATH, 'rb') as f:
@@ -481,6 +501,10 @@ def main():
             del e4, m4
         except Exception as e:       # the C4 leg must never take the headline down with it
             legs['c4'] = dict(error=repr(e))
+        # the other configurations of SURVEY section 8 (C1, C3, C5), short, each in a process of its own (`--config cN`): what a failure or
+        # a hang there costs is that entry, nothing else
+        if a.config == 'c2' and cfg == CONFIGS['c2']:
+            legs['other_configs'] = other_config_legs(('c1', 'c3', 'c5'))
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
