@@ -1125,7 +1125,11 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
     while (nbc > 1 && lds(nbc) > 150 * 1024) --nbc;
     if (lds(nbc) <= 150 * 1024) {
       const dim3 rgrid((g.H + rb - 1) / rb, 3);
-      static const int dbg = [] { const char* e = getenv("APH_SAMPLER_DBG"); return e ? atoi(e) : 0; }();     // (ablation: 1 = no column pass, 2 = no row pass)
+#ifdef APH_EXPERIMENTS      /* ablation hook (1 = no column pass, 2 = no row pass: WRONG gradients) -- only in a -DAPH_EXPERIMENTS build, never in the product library */
+      static const int dbg = [] { const char* e = getenv("APH_SAMPLER_DBG"); return e ? atoi(e) : 0; }();
+#else
+      constexpr int dbg = 0;
+#endif
       const size_t smem = lds(nbc);
 #define APH_ADJ_ROWS(RBQ, CPT)                                                                                                              \
   do {                                                                                                                                       \

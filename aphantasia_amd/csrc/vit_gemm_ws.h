@@ -312,14 +312,14 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
       gemm_load_frags<F>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);    // k-step 0 of unit u+1: overlaps the MFMAs below
     }
     mma(f1);                                                                   // k-step 1 of unit u
-    if (trace && kt == 0 && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 0] = ws_clock();      // first k-tile of a tile done
+    if (trace && kt == 0 && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 0] = ws_clock();      // first k-tile of a tile done
     if (++kt == nk) {
-      if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 1] = ws_clock();                // main loop done
+      if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 1] = ws_clock();      // (slots 14 / 15 hold the entry / exit stamps)                // main loop done
       // epilogue straight from the accumulators (layout: gemm_ws_brow above)
       const int tm = tile / ntn;
       const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = (tile - tm * ntn) * C::BN + wn * 64 + 4 * (lane & 15);
       ws_tiles(epi, m4, M, n4, acc, lbias);
-      if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 2] = ws_clock();                // epilogue issued
+      if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 2] = ws_clock();                // epilogue issued
       kt = 0;
       tile += tile_step;
       if (u + 1 < U) init_tile(tile);
@@ -344,10 +344,22 @@ inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int l
 #endif
   APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles, trace);
 }
+// flag-synchronised variant (vit_gemm_wsf.h): no workgroup barrier in the main loop.  APH_GEMM_WSF / aph_gemm_set_ws_flags() select it for
+// every shape the wave-specialised kernel takes (N <= 3072)
+template <class Epi>
+inline void launch_gemm_wsf(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);
+#ifndef APH_GEMM_WSF_DEFAULT
+#define APH_GEMM_WSF_DEFAULT 0
+#endif
+inline int& gemm_ws_flags() {
+  static int v = [] { const char* e = getenv("APH_GEMM_WSF"); return e ? (atoi(e) != 0 ? 1 : 0) : APH_GEMM_WSF_DEFAULT; }();
+  return v;
+}
 template <class Epi>
 inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                            unsigned long long* trace) {
-  launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace);
+  if (gemm_ws_flags() && !trace && N <= 3072) launch_gemm_wsf(A, lda, Bt, ldb, M, N, K, epi, st);
+  else launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace);
 }
 
 }  // namespace aph

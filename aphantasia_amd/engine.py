@@ -88,7 +88,7 @@ class Engine:
         # static loss scale of the fp16 backward with back-off: an overflowed step (NaN / inf gradient) is skipped on the
         # device (aph_adam_step_guarded); the host looks at the skip counter every GUARD_EVERY steps and halves the scale
         self.loss_scale = float(LOSS_SCALE if loss_scale is None else loss_scale)
-        self._guard_seen, self._guard_host, self._guard_ev, self._guard_rebase = 0, None, None, False
+        self._guard_seen, self._guard_host, self._guard_ev, self._guard_rebase_until = 0, None, None, -1
         self.enforce = float(enforce)                               # clip_fft.py:271-275
         # aest = (weight [D] or [1,D], bias, strength): `loss -= 0.001 * strength * (enc @ w + b).mean()` (clip_fft.py:255-256,
         # utils.py:402-413: the LAION linear aesthetic predictor on the raw encodings)
@@ -211,8 +211,10 @@ class Engine:
                 self._state['step'][0] = 0
                 # skipped-step bookkeeping belongs to the optimiser instance that just ended: a skip reported (up to GUARD_EVERY steps
                 # late) after this point must not be subtracted from the NEW frame's step counter.  The device counter keeps counting
-                # (bench.py reads it); what is re-based is the host's view of it.
-                self._guard_rebase = True
+                # (bench.py reads it); what is re-based is the host's view of it.  The window closes by itself: the counter value read
+                # at call c was copied back at call c - GUARD_EVERY, so a skip of the OLD optimiser can surface in the two read-backs
+                # that follow the reset and in none after them -- a later (genuine) skip of the new frame is subtracted as usual.
+                self._guard_rebase_until = self._calls + 2 * self.GUARD_EVERY
 
     def set_prev_enc(self, enc_rows=None, active=True):
         """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
@@ -393,10 +395,9 @@ class Engine:
         if count > self._guard_seen:
             # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either (not carried across a
             # reset_params: those skips belonged to the previous frame's optimiser)
-            if not self._guard_rebase:
+            if self._calls > self._guard_rebase_until:
                 self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
             self._guard_seen = count
-            self._guard_rebase = False
             self.loss_scale = max(self.loss_scale * 0.5, 1.0)
             self._graphs = None
             print(' fp16 overflow in the backward pass: %d step(s) skipped so far, loss scale -> %g' % (count, self.loss_scale), flush=True)

@@ -52,6 +52,9 @@ int aph_vit_set_fuse_ln(int on);
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
 int aph_gemm_set_ws_min_tiles(int tiles);
+/* 1 = the wave-specialised GEMM hands k-tiles over through LDS counters instead of one workgroup barrier per k-tile
+   (csrc/vit_gemm_wsf.h; environment: APH_GEMM_WSF).  Returns the previous value. */
+int aph_gemm_set_ws_flags(int on);
 /* Pure-MFMA rate probe (bench.py `roofline.peak_measured`): `blocks` workgroups of 8 waves run `iters` x 32 v_mfma_f32_16x16x32_f16 on
  * operands read once from d_src (>= 128 KiB of f16; random data sustains less than zeros: the part is power limited), nothing stored unless a
  * never-true condition holds (d_out: 512 floats).  FLOPs per launch = blocks * 8 * iters * 32 * 16384. */

@@ -10,6 +10,8 @@ Configurations (seeded synthetic ViT-B/32 weights, `-tf none`, sim 'mix', Adam(l
     c2_s200_200  200 cuts, 200 steps         (BASELINE configs[1] verbatim)
     c2_s32       32 cuts, 200 steps          (BASELINE configs[1]'s step count)
     c2_s32_stress  32 cuts, 60 steps, `weights.stress_visual_weights` (LN gains 0.2-10, massive channels, peaky attention)
+    c2_s190_fast 190 cuts, 60 steps, `-tf fast` (transforms.py:165-170 through oracle/augment_ref.apply_fast, the draws interleaved
+                 per cut in the reference's order, utils.py:244-251): the configuration bench.py's headline `value` is measured on
 Both sides draw the crop tables with `R.draw_crop_table` after `seed_all(9)`; the parameters start from
 `R.fft_params_init` after `seed_all(0)` -- exactly what tools/loss_curve.py and the tests do on the GPU side.
 
@@ -27,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from aphantasia_amd.weights import stress_visual_weights, synthetic_visual_weights, visual_config   # noqa: E402  (weights only: no HIP)
-from oracle import clip_vit_ref                                                                    # noqa: E402
+from oracle import augment_ref, clip_vit_ref                                                               # noqa: E402
 from oracle import reference_path as R                                                             # noqa: E402
 
 CONFIGS = {
@@ -35,6 +37,7 @@ CONFIGS = {
     'c2_s200_200': dict(h=720, w=1280, S=200, steps=200, weights='synthetic'),     # BASELINE configs[1] verbatim: samples=200, steps=200 (~45 min of CPU)
     'c2_s32': dict(h=720, w=1280, S=32, steps=200, weights='synthetic'),
     'c2_s32_stress': dict(h=720, w=1280, S=32, steps=60, weights='stress'),
+    'c2_s190_fast': dict(h=720, w=1280, S=190, steps=60, weights='synthetic', tf='fast'),   # --samples 200 -> int(200 * .95) cuts (clip_fft.py:169)
 }
 
 
@@ -65,14 +68,19 @@ def run(name, full_dir=None):
     loss = np.zeros(steps)
     t0 = time.time()
     for i in range(steps):
-        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
-        loss[i] = ref.step(table)
+        if c.get('tf') == 'fast':
+            augs = []
+            table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4, per_cut_hook=lambda _c: augs.append(augment_ref.draw_fast_params(224)))
+            loss[i] = ref.step(table, lambda k, cut: augment_ref.apply_fast(cut, augs[k], R.normalize))
+        else:
+            table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+            loss[i] = ref.step(table)
         if i % 5 == 0 or i == steps - 1:
             print('%s step %d/%d loss %.6f  (%.1f s/step)' % (name, i, steps, loss[i], (time.time() - t0) / (i + 1)), flush=True)
     with torch.no_grad():
         img = ref.image(1.1)[0].float()
-    meta = ('%dx%d ViT-B/32 %s weights (seed 1), %d cuts, -tf none, sim mix, Adam(lr .05, b1 0), %d free-running steps; '
-            'fp32 torch-CPU oracle (ReferenceRun), torch %s, %d threads' % (w, h, c['weights'], S, steps, torch.__version__, torch.get_num_threads()))
+    meta = ('%dx%d ViT-B/32 %s weights (seed 1), %d cuts, -tf %s, sim mix, Adam(lr .05, b1 0), %d free-running steps; '
+            'fp32 torch-CPU oracle (ReferenceRun), torch %s, %d threads' % (w, h, c['weights'], S, c.get('tf', 'none'), steps, torch.__version__, torch.get_num_threads()))
     out = os.path.join(ROOT, 'tests', 'golden', 'loss_curve_%s.npz' % name)
     np.savez_compressed(out, loss=loss, img_blk=block_mean(img).numpy().astype(np.float32), img_mean=img.mean((1, 2)).numpy(),
                         img_std=img.std((1, 2)).numpy(), meta=np.array(meta))

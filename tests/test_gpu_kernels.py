@@ -201,6 +201,41 @@ def test_gemm_wave_specialised_vs_matmul_and_reproducible():
             assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=5), ref), (M, N, Kd, i)
 
 
+def test_gemm_flag_synchronised_vs_matmul_and_reproducible():
+    """tile_cfg 6 (vit_gemm_wsf.h: the wave-specialised kernel with LDS-counter hand-over, no workgroup barrier in the main loop): every
+    ViT-B shape at full batch, ragged / single-unit / shard-size cases against fp32 matmul and against tile_cfg 5 BIT FOR BIT (same tiles,
+    same k order, same epilogue), and the same bits on every launch next to uneven load -- a hand-over race (a stage refilled before a
+    consumer has read it, a unit read before it has landed) shows up as a changing tile"""
+    import torch
+    from aphantasia_amd import ops
+    K.check_gemm(None, DEV, [(9500, 2304, 768), (9500, 768, 768), (9500, 3072, 768), (9500, 768, 3072), (9500, 768, 2304), (70, 128, 64),
+                             (70, 128, 128), (333, 256, 64), (1200, 768, 3072), (18715, 3072, 768)], tile_cfg=6, variants=(0,))
+    g = torch.Generator().manual_seed(7)
+    for (M, N, Kd) in ((9500, 2304, 768), (9500, 768, 3072), (4750, 3072, 768), (9500, 768, 768)):
+        A = torch.randn(M, Kd, generator=g).half().to(DEV); Bt = torch.randn(N, Kd, generator=g).half().to(DEV)
+        ref = ops.gemm_f16(A, Bt, tile_cfg=5).clone()
+        busy = torch.randn(4096, 4096, device=DEV)
+        for i in range(16):
+            if i % 3 == 0:
+                busy = busy * 1.0001
+            assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=6), ref), (M, N, Kd, i)
+
+
+def test_vit_forced_through_the_flag_synchronised_gemm():
+    """all of the ViT's epilogues on gemm_wsf_kernel at small sizes, and bit-identical to the barrier kernel"""
+    from aphantasia_amd import _ffi
+    L = _ffi.lib()
+    prev = L.cdll.aph_gemm_set_ws_min_tiles(1)
+    prevf = L.cdll.aph_gemm_set_ws_flags(1)
+    try:
+        K.check_vit(None, DEV)
+        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
+        K.check_vit(None, DEV, cfg, S=40)
+    finally:
+        L.cdll.aph_gemm_set_ws_min_tiles(prev)
+        L.cdll.aph_gemm_set_ws_flags(prevf)
+
+
 def test_vit_forced_through_the_wave_specialised_gemm():
     """all of the ViT's epilogues on the wave-specialised kernel at small sizes (the default heuristic only takes shapes with >= 160 tiles)"""
     from aphantasia_amd import _ffi

@@ -189,6 +189,60 @@ def test_c2_fast_transform_step_vs_oracle(b32):
     print('C2 -tf fast one step: loss %.6f vs %.6f, grad cos %.6f, max rel %.2e' % (got, want, cos, rel))
 
 
+def test_c2_fast_transform_full_step_190cuts_vs_oracle(b32):
+    """The configuration bench.py's headline `value` is measured on, at its REAL cut count: 1280x720, `--samples 200` -> 190 cuts
+    (clip_fft.py:167-169), `-tf fast` (transforms.py:165-170) with the per-cut draws interleaved in the reference's order
+    (utils.py:244-251): one full step -- loss, spectrum gradient (cosine / max-rel) and the parameters after Adam -- against
+    ReferenceRun.step through oracle/augment_ref.apply_fast (torchvision itself is not in the image: Pillow-pinned geometry)."""
+    h, w, S = 720, 1280, 190
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    seed_all(0)
+    p0 = R.fft_params_init([1, 3, h, w])
+    tgt = target512()
+    eng = Engine(p0.to(DEV).contiguous(), h, w, b32, S, [(tgt, -1.0)], sim='mix', transform=transforms.transforms_fast, rng='reference', use_graph=False)
+    run = R.ReferenceRun(h, w, oracle_encoder(b32), [(tgt, 1.0)], params=p0)
+    seed_all(12)
+    table, augs = draw_crop_params(S, 224, h, w, 'uniform', 0.4, transforms.transforms_fast)
+    seed_all(12)          # the oracle's own restated stream gives the same tables (draw order pinned to the restatement)
+    augs_o = []
+    table_o = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4, per_cut_hook=lambda _c: augs_o.append(augment_ref.draw_fast_params(224)))
+    assert np.array_equal(table, table_o)
+    assert [a['angle'] for a in augs] == [a['angle'] for a in augs_o] and [a['erase'] for a in augs] == [a['erase'] for a in augs_o]
+    npersp, nerase, nrot = sum(a['persp'] is not None for a in augs), sum(a['erase'] is not None for a in augs), sum(a['angle'] != 0 for a in augs)
+    assert npersp >= 20 and nerase >= 20 and nrot >= 100, (npersp, nerase, nrot)
+    got = float(eng.step(table, augs))
+    want = run.step(table_o, per_cut_of(augs_o))
+    assert abs(got - want) < 1e-3, (got, want)
+    cos, rel = compare_grad(eng.grad, run.params.grad, 0.9995, 3e-2)
+    dp = (eng.params.cpu().reshape(-1) - run.params_flat()).abs()
+    frac_off = (dp > 0.02).float().mean().item()
+    print('C2 -tf fast FULL step (190 cuts: %d perspective, %d erase, %d rotated): loss %.6f vs %.6f, grad cos %.6f, max rel %.2e, '
+          'mean |dparam| %.2e, frac(|dparam| > .02) %.2e' % (npersp, nerase, nrot, got, want, cos, rel, dp.mean().item(), frac_off))
+    assert dp.mean().item() < 2e-3 and frac_off < 2e-2
+
+
+def test_c2_fast_loss_curve_190cuts_60steps_vs_oracle_fixture():
+    """The headline configuration FREE-RUNNING: 1280x720, 190 cuts, `-tf fast`, 60 Adam steps from the same init with the reference's
+    per-cut draw order on both sides, against the fp32 CPU oracle's own trajectory (tests/golden/loss_curve_c2_s190_fast.npz,
+    oracle/make_loss_curves.py: ~15 s of host CPU per step, generated once): every step within north_star's 1e-3, final image RMS."""
+    worst, first, rms, _ = _curve('c2_s190_fast')
+    print('C2 -tf fast, 190 cuts, 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f' % (worst, first, rms))
+    assert first is None and worst < 1e-3, (worst, first)
+    assert rms < 0.03, rms
+
+
+# ------------------------------------------------------------------------------------------------ randomised whole steps
+@pytest.mark.parametrize('seed,force', [(41, dict(fast=True)), (42, dict(fast=True, kind='fft')), (43, dict(kind='dwt')), (44, dict(kind='pixel')), (45, None)])
+def test_engine_fuzz_seed(seed, force):
+    """Fixed seeds of the randomised whole-step sweep (tests/engine_fuzz.py; any seed: tools/gpu_engine_fuzz.py): random frame sizes,
+    cut counts, similarity types, optimisers, --align modes and optional loss terms, two free-running steps against the oracle --
+    two seeds forced to `-tf fast`, one to the DWT parameteriser, one to pixels, one unconstrained."""
+    import engine_fuzz as F
+    bad, worst = F.run_seed(F.load_model(), seed, 4, force, DEV)
+    print('engine fuzz seed %d %s: 4 cases, worst |d loss| %.1e' % (seed, force, worst))
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------------------------------------ C3
 def test_c3_dual_model_schedule_vs_oracle(b32, b16):
     """configs[2] on one rank: `-dm 2` -> steps 2, 4 use ViT-B/16 with its own text embedding, the others ViT-B/32; ONE Adam

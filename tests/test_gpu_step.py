@@ -348,6 +348,37 @@ def test_step_is_bitwise_reproducible(model):
     assert a[3] == b[3] == c[3]
 
 
+def test_step_is_bitwise_reproducible_on_the_wave_specialised_gemm(model):
+    """The same tripwire on the kernel that carries 92 of the 98 GEMM launches of the headline step: 100 cuts (M = 5000 token rows) with
+    `aph_gemm_set_ws_min_tiles(1)`, so EVERY ViT GEMM of the step -- one and several tiles per workgroup, the operand ring running across
+    output tiles -- goes through gemm_ws_kernel (vit_gemm_ws.h).  Its counted vmcnt waits / ring hand-offs are what the host interpreter
+    cannot see: two eager runs and one hipGraph run of 5 steps must agree bit for bit."""
+    from aphantasia_amd.engine import Engine
+    from aphantasia_amd import transforms
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    L = _ffi.lib()
+    model.visual.ensure_batch(100)
+    prev = L.cdll.aph_gemm_set_ws_min_tiles(1)
+    try:
+        def run(graph):
+            seed_all(0)
+            h, w = 360, 640
+            params = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
+            eng = Engine(params, h, w, model, 100, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=0.4, use_graph=graph)
+            for _ in range(5):
+                eng.step()
+            torch.cuda.synchronize()
+            return eng.params.clone(), eng.grad.clone(), eng.gpatch.clone(), float(eng.loss)
+        a, b, c = run(False), run(False), run(True)
+    finally:
+        L.cdll.aph_gemm_set_ws_min_tiles(prev)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[:3], c[:3]):          # hipGraph replay == eager launches
+        assert torch.equal(x, y)
+    assert a[3] == b[3] == c[3] and np.isfinite(a[3])
+
+
 def test_f16_patch_gradient_option_is_close(model):
     """Engine(grad_f16=True): the ViT input-gradient crosses to the sampler adjoint as loss-scaled f16 (aph_vit_backward_h +
     APH_GRAD_PATCH_F16); one step stays within f16 rounding of the default f32 hand-over"""

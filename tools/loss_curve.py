@@ -3,7 +3,7 @@ to 1e-3") at BASELINE configs[1]'s real workload.  Both sides take their own Ada
 tables; the oracle's trajectory comes from the committed fixture tests/golden/loss_curve_<name>.npz (oracle/make_loss_curves.py:
 8-18 s of host CPU per 200-cut step, generated once instead of on GPU-box minutes).
 
-    python tools/loss_curve.py <name> [csv-out] [final-image-out.npy]       name in c2_s200 | c2_s32 | c2_s32_stress
+    python tools/loss_curve.py <name> [csv-out] [final-image-out.npy]       name in c2_s200 | c2_s200_200 | c2_s32 | c2_s32_stress | c2_s190_fast
     python tools/loss_curve.py --live H W S STEPS                            oracle run side by side (small cases)
 
 The CSV holds per-step loss_hip, loss_oracle, |diff|; the trailer the maximum, the first step (if any) past 1e-3, and the RMS of the
@@ -29,7 +29,7 @@ def block_mean(img, k=4):
     return img[:, :h // k * k, :w // k * k].reshape(c, h // k, k, w // k, k).mean((2, 4))
 
 
-def hip_engine(h, w, S, weights='synthetic', **kw):
+def hip_engine(h, w, S, weights='synthetic', transform=None, **kw):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model, _ = aclip.load('ViT-B/32', seed=1, max_batch=S)
@@ -38,7 +38,7 @@ def hip_engine(h, w, S, weights='synthetic', **kw):
     seed_all(0)
     p0 = R.fft_params_init([1, 3, h, w])
     target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
-    eng = Engine(p0.cuda().contiguous(), h, w, model, S, [(target, -1.0)], sim='mix', transform=transforms.normalize(), rng='reference', **kw)
+    eng = Engine(p0.cuda().contiguous(), h, w, model, S, [(target, -1.0)], sim='mix', transform=transform or transforms.normalize(), rng='reference', **kw)
     return eng, model, p0, target
 
 
@@ -50,12 +50,18 @@ def run_fixture(name, csv_out=None, img_out=None, steps=None, **kw):
     h, w = 720, 1280
     S = int(meta.split(' cuts')[0].split(', ')[-1])
     steps = len(want) if steps is None else min(steps, len(want))
-    eng, _, _, _ = hip_engine(h, w, S, 'stress' if 'stress' in name else 'synthetic', **kw)
+    fast = '-tf fast' in meta          # the per-cut augment draws interleave with the crop draws in the reference's order (utils.py:244-251)
+    eng, _, _, _ = hip_engine(h, w, S, 'stress' if 'stress' in name else 'synthetic', transforms.transforms_fast if fast else None, **kw)
     seed_all(9)
     got = np.zeros(steps)
     for i in range(steps):
-        table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
-        got[i] = float(eng.step(table))
+        if fast:
+            from aphantasia_amd.utils import draw_crop_params
+            table, augs = draw_crop_params(S, 224, h, w, 'uniform', 0.4, transforms.transforms_fast)
+            got[i] = float(eng.step(table, augs))
+        else:
+            table = R.draw_crop_table(S, 224, h, w, 'uniform', 0.4)
+            got[i] = float(eng.step(table))
     diff = np.abs(got - want[:steps])
     over = np.nonzero(diff > 1e-3)[0]
     rms = None
