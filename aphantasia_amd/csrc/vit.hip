@@ -12,8 +12,6 @@
 #include "aph_host.h"
 #include "vit_gemm.h"
 #include "vit_gemm_ws.h"
-#include "vit_gemm_wsf.h"
-#include "vit_gemm_deep.h"
 #include "vit_ops.h"
 #include "vit_attn.h"
 
@@ -436,11 +434,10 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
   return prev;
 }
 
-// 1 = the wave-specialised GEMM hands its k-tiles over through LDS counters instead of a workgroup barrier per k-tile (vit_gemm_wsf.h).
-// Returns the previous value.
-int aph_gemm_set_ws_flags(int on) {
-  const int prev = gemm_ws_flags();
-  gemm_ws_flags() = on ? 1 : 0;
+// row panels per tile-order group of the wave-specialised GEMM (vit_gemm_ws.h `coords`): 0 = automatic, k > 0 = force.  Returns the previous value.
+int aph_gemm_set_ws_pgroup(int g) {
+  const int prev = gemm_ws_pgroup_override();
+  gemm_ws_pgroup_override() = g < 0 ? 0 : g;
   return prev;
 }
 
@@ -528,15 +525,15 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 }
 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
-// (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 5 = 256x128 wave-specialised persistent, 6 = the same with LDS-counter hand-over instead of barriers (vit_gemm_wsf.h), 8 / 9 = 64x64 split-K x2 / x4,
-// 10 = 128x128 4-stage, 11 = 128x128 4 waves 2-stage (two workgroups per CU), 12 = 256x128 on 4 waves, 13 = 64x64 with an 8-stage ring (vit_gemm_deep.h),
+// (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 5 = 256x128 wave-specialised persistent, 8 / 9 = 64x64 split-K x2 / x4,
+// 10 = 128x128 4-stage, 11 = 128x128 4 waves 2-stage (two workgroups per CU), 12 = 256x128 on 4 waves,
 // 22 / 24 = 128x128 split-K x2 / x4) -- unit tests and tuning sweeps
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   const bool nostore = (tile_cfg & 0x100) != 0;
   tile_cfg &= 0xff;
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || tile_cfg == 6 || (tile_cfg >= 8 && tile_cfg <= 13) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)) || (tile_cfg == 6 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWSF::BIAS_MAX)))
+      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || tile_cfg == 22 || tile_cfg == 24) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
@@ -547,15 +544,13 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
     if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, en, st);
     else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, en, st);
     else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, en, st, nullptr);
-    else if (tile_cfg == 6) launch_gemm_wsf_cfg<GemmWSF>(A, lda, B, ldb, M, N, K, en, st);
-    else return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: the no-store variant exists for tile_cfg 2, 4, 5 and 6");
+    else return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: the no-store variant exists for tile_cfg 2, 4 and 5");
     return aph_check_launch("aph_gemm_f16_ld");
   }
   if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, epi, st, nullptr);
-  else if (tile_cfg == 6) launch_gemm_wsf_cfg<GemmWSF>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 8 || tile_cfg == 9 || tile_cfg == 22 || tile_cfg == 24) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
     static SplitKSpace sp;
     const int splits = (tile_cfg == 8 || tile_cfg == 22) ? 2 : 4;
@@ -570,7 +565,6 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 10) launch_gemm_cfg<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 11) launch_gemm_cfg<GemmPair>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 12) launch_gemm_cfg<GemmFat>(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 13) launch_gemm_cfg<GemmSmallDeep>(A, lda, B, ldb, M, N, K, epi, st);
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH

@@ -689,6 +689,9 @@ struct SplitKSpace {
 // how many ways to split K for the 64x64 configuration: only when the tiles alone occupy a small part of the chip (the
 // class-row GEMMs: M = cuts) and the k loop is long; every share keeps >= 6 k-tiles.  At M ~ 1200 (228 tiles) the
 // 64x64 tiles are bound by L2-miss bandwidth on the weight panel, and splitting K was measured to lose (18 -> 21 us).
+// (Round 4, profiles/r04_small_m_deep_ring.txt: an EIGHT-stage ring for the 64x64 configuration -- seven k-tiles in flight per CU, one workgroup
+// per CU -- was the queued experiment for M = 1200: slower on every ViT shape, 19.8 vs 13.5 us on QKV, 19.7 vs 17.9 on fc2: these k loops are
+// not short of requests in flight; two co-resident 4-stage workgroups hide more than one deep ring.  Removed.)
 inline int choose_splits(int M, int N, int K, const SplitKSpace* sp) {
   if (!sp || !sp->ws) return 1;
   const int tiles = (N / GemmSmall::BN) * ((M + GemmSmall::BM - 1) / GemmSmall::BM), nk = K / GEMM_BK;

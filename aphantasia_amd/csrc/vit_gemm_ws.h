@@ -194,7 +194,7 @@ __device__ __forceinline__ void ws_wait_barrier(int ahead) {      // all but the
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
-                                                                  int ldb, int M, int N, int K, Epi epi, int ntiles, unsigned long long* __restrict__ trace) {
+                                                                  int ldb, int M, int N, int K, Epi epi, int ntiles, int pgroup, unsigned long long* __restrict__ trace) {
   using F = GemmBig;                             // fragment shapes of a consumer wave: 4 x 4 MFMA tiles (64 x 64)
   APH_DYN_SMEM(smem);
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -215,8 +215,21 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   }
   if (tile >= tile_end) return;                  // (workgroup-uniform; does not happen with gridDim.x <= ntiles)
   if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 15) * 4 + 3] = ws_realtime();   // kernel entry, chip-wide 100 MHz clock
-  const int nk = K / GEMM_BK, ntn = N / C::BN;
+  const int nk = K / GEMM_BK, ntn = N / C::BN, ntm = ntiles / ntn;
   const int U = ((tile_end - tile + tile_step - 1) / tile_step) * nk;       // k-tile units of this workgroup
+  // Tile order inside the XCD runs: groups of `pgroup` row panels; inside a group the tiles of ONE column tile across the group's panels
+  // are consecutive, then the next column tile.  The 32 workgroups of an XCD work on 32 consecutive tiles, i.e. on pgroup row panels x
+  // (32 / pgroup) column tiles: with pgroup = 4 that is 1.5 MB of A panels + 1.5 MB of weight rows -- it fits the XCD's 4 MiB L2, and a
+  // weight tile is fetched from the fabric once per FOUR row panels instead of once per panel (n-fastest order, pgroup = 1: 32 consecutive
+  // tiles = 1.3-1.8 panels x all of W, 3.5-4.7 MB at N = 2304 / 3072, which the L2 cannot hold next to the A panels: 284 MB of fabric
+  // traffic per fc1 launch for 136 MB algorithmic, profiles/r03_pmc_hbm_traffic.json).  The runs and their lengths are unchanged, so the
+  // balance of the persistent walk is too (what the per-XCD rectangle order of round 3 lost).
+  auto coords = [&](int t, int& tm, int& tn) {
+    const int per = pgroup * ntn, g = t / per, rem = t - g * per;
+    const int left = ntm - g * pgroup, rg = left < pgroup ? left : pgroup;
+    tn = rem / rg;
+    tm = g * pgroup + (rem - tn * rg);
+  };
   // the epilogue's bias vector goes to LDS behind the ring once (N <= 4096 floats); visible after the first barrier
   float* lbias = reinterpret_cast<float*>(smem + C::SMEM);
   if (const float* gb = ws_bias(epi)) {
@@ -231,7 +244,9 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(Bt);
     auto setup = [&](int t) {
-      const int tm = t / ntn, n0 = (t - tm * ntn) * C::BN, m0 = tm * C::BM;
+      int tm, tn;
+      coords(t, tm, tn);
+      const int n0 = tn * C::BN, m0 = tm * C::BM;
 #pragma unroll
       for (int i = 0; i < C::QPW; ++i) {
         if (i < C::QAW) {
@@ -287,8 +302,9 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   int kt = 0, st = 0;
   wait_vm_barrier<63>();                                                       // unit 0 has landed (and the bias vector is in LDS)
   auto init_tile = [&](int t) {
-    const int tm = t / ntn;
-    const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = (t - tm * ntn) * C::BN + wn * 64 + 4 * (lane & 15);
+    int tm, tn;
+    coords(t, tm, tn);
+    const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = tn * C::BN + wn * 64 + 4 * (lane & 15);
 #pragma unroll
     for (int mt = 0; mt < F::TM; ++mt) ws_init(epi, m4 + mt * 16, M, n4, acc[mt], lbias);
   };
@@ -316,8 +332,9 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     if (++kt == nk) {
       if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 1] = ws_clock();      // (slots 14 / 15 hold the entry / exit stamps)                // main loop done
       // epilogue straight from the accumulators (layout: gemm_ws_brow above)
-      const int tm = tile / ntn;
-      const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = (tile - tm * ntn) * C::BN + wn * 64 + 4 * (lane & 15);
+      int tm, tn;
+      coords(tile, tm, tn);
+      const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = tn * C::BN + wn * 64 + 4 * (lane & 15);
       ws_tiles(epi, m4, M, n4, acc, lbias);
       if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 2] = ws_clock();                // epilogue issued
       kt = 0;
@@ -326,6 +343,18 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     }
   }
   if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 14) * 4 + 3] = ws_realtime();     // consumer wave 0 done
+}
+
+// row panels per tile-order group (see `coords` in the kernel): 4 when more than one round of tiles shares the weights (wide outputs), 1 = the
+// plain n-fastest order otherwise.  APH_GEMM_WS_PGROUP / aph_gemm_set_ws_pgroup(): 0 = automatic, k > 0 = force k (A/B measurements)
+inline int& gemm_ws_pgroup_override() {
+  static int v = [] { const char* e = getenv("APH_GEMM_WS_PGROUP"); return e ? atoi(e) : 0; }();
+  return v;
+}
+inline int gemm_ws_panel_group(int ntn, int ntm) {
+  int g = gemm_ws_pgroup_override();
+  if (g <= 0) g = ntn >= 12 ? 4 : 1;
+  return g < ntm ? g : (ntm > 0 ? ntm : 1);
 }
 
 template <class C, class Epi>
@@ -342,24 +371,19 @@ inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int l
     fprintf(stderr, "gemm_ws_kernel<BM %d>: occupancy API says %d workgroup(s) per CU (threads %d, LDS %d)\n", C::BM, nb, C::NTHREAD, C::SMEM_TOTAL);
   }
 #endif
-  APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles, trace);
+  APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles,
+             gemm_ws_panel_group(N / C::BN, (M + C::BM - 1) / C::BM), trace);
 }
-// flag-synchronised variant (vit_gemm_wsf.h): no workgroup barrier in the main loop.  APH_GEMM_WSF / aph_gemm_set_ws_flags() select it for
-// every shape the wave-specialised kernel takes (N <= 3072)
-template <class Epi>
-inline void launch_gemm_wsf(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);
-#ifndef APH_GEMM_WSF_DEFAULT
-#define APH_GEMM_WSF_DEFAULT 0
-#endif
-inline int& gemm_ws_flags() {
-  static int v = [] { const char* e = getenv("APH_GEMM_WSF"); return e ? (atoi(e) != 0 ? 1 : 0) : APH_GEMM_WSF_DEFAULT; }();
-  return v;
-}
+// (Measured and rejected in round 4, profiles/r04_ab_gemm_flag_sync.txt: the same kernel with NO workgroup barrier in the main loop -- producers and
+// consumers handing k-tile units over through counters in LDS (ready[producer] after a counted vmcnt wait, done[consumer] after lgkmcnt(0), the
+// consumers asking for the counters behind their fragment reads, the producers polling with s_sleep), so that waves drift by up to the ring
+// depth and a wave's epilogue sits under its SIMD partner's MFMAs.  Bit-identical results, 14-34 % SLOWER per shape (QKV 58.9 vs 43.8 us, fc2
+// 55.2 vs 48.3), whole step 150.5 vs 162.8 steps/s: a stage is refilled only when the SLOWEST consumer has released it while the fastest one
+// already wants the unit after next -- the skew the barrier forbids is paid for out of the 3-stage ring.  git show e138f33:aphantasia_amd/csrc/vit_gemm_wsf.h)
 template <class Epi>
 inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                            unsigned long long* trace) {
-  if (gemm_ws_flags() && !trace && N <= 3072) launch_gemm_wsf(A, lda, Bt, ldb, M, N, K, epi, st);
-  else launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace);
+  launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace);
 }
 
 }  // namespace aph

@@ -228,7 +228,7 @@ def lib_sha():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-GEMM_SOURCES = ('aph_device.h', 'aph_host.h', 'vit_gemm.h', 'vit_gemm_ws.h', 'vit_gemm_deep.h', 'vit_ops.h', 'vit_attn.h', 'vit.hip')   # the whole ViT translation unit: GEMM kernels, launch heuristic, launch sites / epilogue choice
+GEMM_SOURCES = ('aph_device.h', 'aph_host.h', 'vit_gemm.h', 'vit_gemm_ws.h', 'vit_ops.h', 'vit_attn.h', 'vit.hip')   # the whole ViT translation unit: GEMM kernels, launch heuristic, launch sites / epilogue choice
 
 
 def gemm_src_sha():

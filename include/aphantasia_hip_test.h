@@ -28,7 +28,6 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
  *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
- *   13  64x64, 4 waves, 8-stage ring (seven k-tiles in flight per CU: the small-M experiment of vit_gemm_deep.h; not yet measured on hardware)
  *   22 / 24  128x128 split-K x2 / x4
  * | 0x100 (with 2, 4 or 5 only): measurement variant whose epilogue keeps the accumulators live but never stores (upper bound of
  *   what overlapping the store phase could gain: tools/exp/gemm_nostore.py).
@@ -52,9 +51,9 @@ int aph_vit_set_fuse_ln(int on);
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* 1 = the wave-specialised GEMM hands k-tiles over through LDS counters instead of one workgroup barrier per k-tile
-   (csrc/vit_gemm_wsf.h; environment: APH_GEMM_WSF).  Returns the previous value. */
-int aph_gemm_set_ws_flags(int on);
+/* Tile order of the wave-specialised GEMM inside an XCD's run: groups of g row panels, column tile by column tile inside a group
+ * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest; environment APH_GEMM_WS_PGROUP).  Returns the previous value. */
+int aph_gemm_set_ws_pgroup(int g);
 /* Pure-MFMA rate probe (bench.py `roofline.peak_measured`): `blocks` workgroups of 8 waves run `iters` x 32 v_mfma_f32_16x16x32_f16 on
  * operands read once from d_src (>= 128 KiB of f16; random data sustains less than zeros: the part is power limited), nothing stored unless a
  * never-true condition holds (d_out: 512 floats).  FLOPs per launch = blocks * 8 * iters * 32 * 16384. */

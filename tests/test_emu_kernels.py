@@ -102,12 +102,16 @@ def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(70, 128, 192)], tile_cfg=8)
     K.check_gemm(emu, 'cpu', [(200, 256, 320)], tile_cfg=10)   # 128x128, 8 waves, 4-stage ring
     K.check_gemm(emu, 'cpu', [(70, 128, 64)], tile_cfg=2)     # single k-tile, single partial tile
-    K.check_gemm(emu, 'cpu', [(150, 128, 768), (64, 128, 128), (70, 128, 64), (130, 256, 448)], tile_cfg=13, variants=(0,))   # 64x64, 8-stage ring (experiment, vit_gemm_deep.h): 12 / 2 / 1 / 7 k-tiles
     # wave-specialised persistent kernel (vit_gemm_ws.h): producer / consumer waves, permuted Bt rows, register epilogue;
     # single unit, ragged single tile, 9 / 10 tiles on 3 workgroups with odd and even k-tile counts
     K.check_gemm(emu, 'cpu', [(70, 128, 64), (300, 256, 192), (700, 768, 192), (1100, 512, 128)], tile_cfg=5, variants=(0,))
-    # the same kernel with LDS-counter hand-over instead of a workgroup barrier per k-tile (vit_gemm_wsf.h): same cases + 2 / 7 k-tile units
-    K.check_gemm(emu, 'cpu', [(70, 128, 64), (70, 128, 128), (300, 256, 192), (700, 768, 192), (1100, 512, 128), (130, 256, 448)], tile_cfg=6, variants=(0,))
+    # panel-grouped tile order (groups of 2 / 4 row panels, ragged last group: 3 and 5 panels)
+    for g in (2, 4):
+        prev = emu.cdll.aph_gemm_set_ws_pgroup(g)
+        try:
+            K.check_gemm(emu, 'cpu', [(700, 768, 64), (1100, 512, 128), (70, 128, 64)], tile_cfg=5, variants=(0,))
+        finally:
+            emu.cdll.aph_gemm_set_ws_pgroup(prev)
 
 
 def test_vit_through_the_wave_specialised_gemm(emu):
@@ -120,19 +124,6 @@ def test_vit_through_the_wave_specialised_gemm(emu):
         K.check_vit(emu, 'cpu', cfg, S=20, check_fuse=False)        # M = 340: two row tiles, the second ragged
     finally:
         emu.cdll.aph_gemm_set_ws_min_tiles(prev)
-
-
-def test_vit_through_the_flag_synchronised_gemm(emu):
-    """the same with aph_gemm_set_ws_flags(1): every ViT epilogue on gemm_wsf_kernel (vit_gemm_wsf.h)"""
-    prev = emu.cdll.aph_gemm_set_ws_min_tiles(1)
-    prevf = emu.cdll.aph_gemm_set_ws_flags(1)
-    try:
-        K.check_vit(emu, 'cpu', check_fuse=False)
-        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
-        K.check_vit(emu, 'cpu', cfg, S=20, check_fuse=False)
-    finally:
-        emu.cdll.aph_gemm_set_ws_min_tiles(prev)
-        emu.cdll.aph_gemm_set_ws_flags(prevf)
 
 
 def test_vit(emu):

@@ -168,21 +168,6 @@ def test_gemm_every_tile_config():
     K.check_gemm(None, DEV, [(9500, 3072, 768), (18715, 3072, 768)], tile_cfg=4, variants=(0,))   # persistent loop: 456 / 888 tiles on 256 CUs
 
 
-@pytest.mark.skipif(os.environ.get('APH_TEST_EXPERIMENTS') != '1', reason='tile_cfg 13 (8-stage ring, vit_gemm_deep.h) has not run on hardware yet: '
-                    'APH_TEST_EXPERIMENTS=1 enables its first GPU check (the counted vmcnt waits are what the interpreter cannot see)')
-def test_gemm_deep_ring_experiment_vs_matmul_and_reproducible():
-    K.check_gemm(None, DEV, [(1200, 768, 768), (1200, 768, 3072), (1200, 2304, 768), (333, 256, 64), (64, 128, 128)], tile_cfg=13, variants=(0,))
-    A = torch.randn(1200, 3072, device=DEV).half()
-    B = torch.randn(768, 3072, device=DEV).half()
-    outs = []
-    for _ in range(20):
-        C = torch.empty(1200, 768, device=DEV)
-        _ffi.lib().call('aph_gemm_f16_ld', ops.ptr(A), 3072, ops.ptr(B), 3072, 1200, 768, 3072, ops.ptr(C), 13, ops._stream(C))
-        outs.append(C)
-    torch.cuda.synchronize()
-    assert all(torch.equal(outs[0], o) for o in outs[1:])      # an under-waited DMA shows up as run-to-run differences
-
-
 def test_gemm_wave_specialised_vs_matmul_and_reproducible():
     """tile_cfg 5 (vit_gemm_ws.h): every ViT-B shape at full batch and ragged / single-tile cases against fp32 matmul, and the SAME BITS
     on every launch -- the interpreter cannot see a vmcnt under-wait or a stage refilled too early; a race shows up here as a changing tile"""
@@ -199,41 +184,19 @@ def test_gemm_wave_specialised_vs_matmul_and_reproducible():
             if i % 3 == 0:
                 busy = busy * 1.0001          # uneven load next to the launches
             assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=5), ref), (M, N, Kd, i)
-
-
-def test_gemm_flag_synchronised_vs_matmul_and_reproducible():
-    """tile_cfg 6 (vit_gemm_wsf.h: the wave-specialised kernel with LDS-counter hand-over, no workgroup barrier in the main loop): every
-    ViT-B shape at full batch, ragged / single-unit / shard-size cases against fp32 matmul and against tile_cfg 5 BIT FOR BIT (same tiles,
-    same k order, same epilogue), and the same bits on every launch next to uneven load -- a hand-over race (a stage refilled before a
-    consumer has read it, a unit read before it has landed) shows up as a changing tile"""
-    import torch
-    from aphantasia_amd import ops
-    K.check_gemm(None, DEV, [(9500, 2304, 768), (9500, 768, 768), (9500, 3072, 768), (9500, 768, 3072), (9500, 768, 2304), (70, 128, 64),
-                             (70, 128, 128), (333, 256, 64), (1200, 768, 3072), (18715, 3072, 768)], tile_cfg=6, variants=(0,))
-    g = torch.Generator().manual_seed(7)
-    for (M, N, Kd) in ((9500, 2304, 768), (9500, 768, 3072), (4750, 3072, 768), (9500, 768, 768)):
-        A = torch.randn(M, Kd, generator=g).half().to(DEV); Bt = torch.randn(N, Kd, generator=g).half().to(DEV)
-        ref = ops.gemm_f16(A, Bt, tile_cfg=5).clone()
-        busy = torch.randn(4096, 4096, device=DEV)
-        for i in range(16):
-            if i % 3 == 0:
-                busy = busy * 1.0001
-            assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=6), ref), (M, N, Kd, i)
-
-
-def test_vit_forced_through_the_flag_synchronised_gemm():
-    """all of the ViT's epilogues on gemm_wsf_kernel at small sizes, and bit-identical to the barrier kernel"""
+    # the tile ORDER does not change a tile's arithmetic: n-fastest (1) == groups of 2 / 4 / 5 row panels, bit for bit
     from aphantasia_amd import _ffi
     L = _ffi.lib()
-    prev = L.cdll.aph_gemm_set_ws_min_tiles(1)
-    prevf = L.cdll.aph_gemm_set_ws_flags(1)
-    try:
-        K.check_vit(None, DEV)
-        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
-        K.check_vit(None, DEV, cfg, S=40)
-    finally:
-        L.cdll.aph_gemm_set_ws_min_tiles(prev)
-        L.cdll.aph_gemm_set_ws_flags(prevf)
+    A = torch.randn(9500, 768, generator=g).half().to(DEV); Bt = torch.randn(3072, 768, generator=g).half().to(DEV)
+    outs = []
+    for pg in (1, 2, 4, 5):
+        prev = L.cdll.aph_gemm_set_ws_pgroup(pg)
+        try:
+            outs.append(ops.gemm_f16(A, Bt, tile_cfg=5).clone())
+        finally:
+            L.cdll.aph_gemm_set_ws_pgroup(prev)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert (outs[0] - A.float() @ Bt.float().T).abs().max().item() < 2e-3 * (768 / 64) ** 0.5
 
 
 def test_vit_forced_through_the_wave_specialised_gemm():
