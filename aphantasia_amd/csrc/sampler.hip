@@ -60,11 +60,15 @@ __device__ __forceinline__ int wrap(int v, int n) {
   return v;
 }
 
-// patch-major element offset of pixel (c,i,j) of cut s.  The patch side p is a power of two (checked on the host):
-// shifts and masks instead of integer divisions in the per-pixel index arithmetic.
+// patch-major element offset of pixel (c,i,j) of cut s.  [r4] Inside a patch row the order is PIXEL-major, channel fastest:
+//     k = ((i mod p) * p + (j mod p)) * 3 + c          (openai/CLIP's conv1.weight flattens as (c, i, j): aph_vit_set_weight permutes its
+// columns once at load time -- the GEMM does not care in which order K is summed).  The three channels of a pixel are then 6 (f16) / 12 (f32)
+// contiguous bytes: one access per bilinear tap / candidate in the warp adjoints instead of three 4-byte gathers at a 4 KiB stride (the kernels
+// are bound by the L1's access rate), and one contiguous run per lane pair in the emit.  The patch side p is a power of two (checked on the
+// host): shifts and masks instead of integer divisions in the per-pixel index arithmetic.
 __device__ __forceinline__ size_t patch_index(int s, int c, int i, int j, int size, int p) {
   const int lp = __ffs(p) - 1, g = size >> lp;
-  return ((size_t)s * g * g + (size_t)(i >> lp) * g + (j >> lp)) * (size_t)(3 << (2 * lp)) + ((size_t)c << (2 * lp)) + ((i & (p - 1)) << lp) + (j & (p - 1));
+  return ((size_t)s * g * g + (size_t)(i >> lp) * g + (j >> lp)) * (size_t)(3 << (2 * lp)) + (size_t)((((i & (p - 1)) << lp) + (j & (p - 1))) * 3 + c);
 }
 
 template <int OUT>
@@ -87,6 +91,18 @@ __device__ __forceinline__ float gload(const void* __restrict__ g, size_t o) {
 }
 template <int OUT>
 struct is_patch { static constexpr bool v = OUT == APH_OUT_PATCH_F16 || OUT == APH_GRAD_PATCH_F16; };
+// the three channels of one pixel of a patch-major gradient (contiguous: one 12-byte load for f32)
+struct __attribute__((packed, aligned(4))) F3u { float v[3]; };
+template <int OUT>
+__device__ __forceinline__ void gload3(const void* __restrict__ g, size_t o, float q[3]) {
+  if (OUT == APH_GRAD_PATCH_F16) {
+    const half_t* h = reinterpret_cast<const half_t*>(g) + o;
+    q[0] = (float)h[0]; q[1] = (float)h[1]; q[2] = (float)h[2];
+  } else {
+    const F3u t = *reinterpret_cast<const F3u*>(reinterpret_cast<const float*>(g) + o);
+    q[0] = t.v[0]; q[1] = t.v[1]; q[2] = t.v[2];
+  }
+}
 // internal layout of the per-cut scratch of the FORWARD augment chain (never crosses the C ABI): f32 [S][size][size][4] = (r, g, b, pad).
 // Every bilinear tap of the perspective / rotation warps is then ONE 16-byte access for the three channels instead of three 4-byte
 // ones in three planes (the warps are bound by L1 line accesses: crop + persp + rotate 311 -> 280 us at C2).  The ADJOINT chain keeps
@@ -107,8 +123,9 @@ template <int OUT>
 __device__ __forceinline__ void fetch_grad3(const void* __restrict__ gout, int s, int i, int j, int size, int patch, float g[3]) {
   if (is_patch<OUT>::v) {
     const size_t o = patch_index(s, 0, i, j, size, patch);
-    const int pp = patch * patch;
-    g[0] = gload<OUT>(gout, o) / kClipStd[0]; g[1] = gload<OUT>(gout, o + pp) / kClipStd[1]; g[2] = gload<OUT>(gout, o + 2 * pp) / kClipStd[2];
+    float q[3];
+    gload3<OUT>(gout, o, q);
+    g[0] = q[0] / kClipStd[0]; g[1] = q[1] / kClipStd[1]; g[2] = q[2] / kClipStd[2];
   } else {
     const size_t o = ((size_t)s * 3 * size + i) * size + j, nn = (size_t)size * size;
     g[0] = gload<OUT>(gout, o); g[1] = gload<OUT>(gout, o + nn); g[2] = gload<OUT>(gout, o + 2 * nn);
@@ -120,12 +137,10 @@ __device__ __forceinline__ void emit3(void* out, int s, int i, int j, int size, 
   if (OUT == APH_SCRATCH_HWC4) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + hwc4_index(s, i, j, size)) = f32x4{v0, v1, v2, 0.f};
   } else if (OUT == APH_OUT_PATCH_F16) {
-    const size_t o = patch_index(s, 0, i, j, size, patch);
-    const int pp = patch * patch;
-    half_t* q = reinterpret_cast<half_t*>(out);
-    q[o] = (half_t)((v0 - kClipMean[0]) / kClipStd[0]);
-    q[o + pp] = (half_t)((v1 - kClipMean[1]) / kClipStd[1]);
-    q[o + 2 * pp] = (half_t)((v2 - kClipMean[2]) / kClipStd[2]);
+    half_t* q = reinterpret_cast<half_t*>(out) + patch_index(s, 0, i, j, size, patch);
+    q[0] = (half_t)((v0 - kClipMean[0]) / kClipStd[0]);
+    q[1] = (half_t)((v1 - kClipMean[1]) / kClipStd[1]);
+    q[2] = (half_t)((v2 - kClipMean[2]) / kClipStd[2]);
   } else {
     emit<OUT>(out, s, 0, i, j, size, patch, v0);
     emit<OUT>(out, s, 1, i, j, size, patch, v1);
@@ -258,12 +273,12 @@ struct AdjEntry {
 // separable offset parts of gradient element (i, j) in layout OUT (channel/cut base added by the caller)
 template <int OUT>
 __device__ __forceinline__ int grad_rowpart(int i, int size, int p) {
-  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (i >> lp) * (size >> lp) * (3 << (2 * lp)) + ((i & (p - 1)) << lp); }
+  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (i >> lp) * (size >> lp) * (3 << (2 * lp)) + ((i & (p - 1)) << lp) * 3; }
   return i * size;
 }
 template <int OUT>
 __device__ __forceinline__ int grad_colpart(int j, int /*size*/, int p) {
-  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (j >> lp) * (3 << (2 * lp)) + (j & (p - 1)); }
+  if (is_patch<OUT>::v) { const int lp = __ffs(p) - 1; return (j >> lp) * (3 << (2 * lp)) + (j & (p - 1)) * 3; }
   return j;
 }
 
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void crop_resize_adjoint_kernel(const void* __
   const int nay = (g.Hp + g.H - 1) / g.H, nax = (g.Wp + g.W - 1) / g.W;     // aliases per axis (1 without overscan)
   const int nvirt = g.S * nay * nax;
   const int ty0 = by_ * 16, tx0 = bx_ * 16;
-  const int cchan = is_patch<OUT>::v ? g.patch * g.patch : g.size * g.size;
+  const int cchan = is_patch<OUT>::v ? 1 : g.size * g.size;       // channel stride of the gradient layout (patch-major: channel fastest)
   const int ccut = is_patch<OUT>::v ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
   for (int vbase = 0; vbase < nvirt; vbase += MAXV) {
@@ -487,7 +502,7 @@ __device__ __forceinline__ int grad_row_of_off(int off, int size, int p) {
   if (is_patch<OUT>::v) {
     const int lp = __ffs(p) - 1, rs = (size >> lp) * (3 << (2 * lp));
     const int ip = off / rs;
-    return (ip << lp) + ((off - ip * rs) >> lp);
+    return (ip << lp) + (off - ip * rs) / (3 << lp);
   }
   return off / size;
 }
@@ -497,7 +512,7 @@ __device__ __forceinline__ int grad_col_of_off(int off, int p) {         // inve
   if (is_patch<OUT>::v) {
     const int lp = __ffs(p) - 1;
     const int jp = ((off >> (2 * lp)) * 43) >> 7;      // / 3 for values < 128 (at most size / patch = 7 .. 14 patch columns)
-    return (jp << lp) + (off - jp * (3 << (2 * lp)));
+    return (jp << lp) + (((off - jp * (3 << (2 * lp))) * 43) >> 7);      // 3 (j mod p) < 128 as well (p <= 32)
   }
   return off;
 }
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.y, y0 = blockIdx.x * RB;
   const int rows = g.H - y0 < RB ? g.H - y0 : RB;
-  const int cchan = is_patch<OUT>::v ? g.patch * g.patch : g.size * g.size;
+  const int cchan = is_patch<OUT>::v ? 1 : g.size * g.size;       // channel stride of the gradient layout (patch-major: channel fastest)
   const int ccut = is_patch<OUT>::v ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
   f32x4 acc[CPT][RBQ];
 #pragma unroll
@@ -913,8 +928,8 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
           const float x = -fn * 0.5f + 0.5f + (float)jc, y = -fn * 0.5f + 0.5f + (float)ic;
           gxj[t] = x * ka; gyj[t] = x * -kb;
           gxi[t] = y * kb; gyi[t] = y * ka;
-          colo[t] = is_patch<OUT>::v ? (size_t)(jc >> lp) * (size_t)(3 << (2 * lp)) + (jc & (patch - 1)) : (size_t)jc;
-          rowo[t] = is_patch<OUT>::v ? (size_t)(ic >> lp) * pg * (size_t)(3 << (2 * lp)) + ((ic & (patch - 1)) << lp) : (size_t)ic * n;
+          colo[t] = is_patch<OUT>::v ? (size_t)(jc >> lp) * (size_t)(3 << (2 * lp)) + (size_t)(jc & (patch - 1)) * 3 : (size_t)jc;
+          rowo[t] = is_patch<OUT>::v ? (size_t)(ic >> lp) * pg * (size_t)(3 << (2 * lp)) + (size_t)((ic & (patch - 1)) << lp) * 3 : (size_t)ic * n;
         }
         const size_t base = is_patch<OUT>::v ? (size_t)s * pg * pg * (size_t)(3 << (2 * lp)) : (size_t)s * 3 * n * n;
         const float fpx = (float)px, fpy = (float)py;
@@ -930,11 +945,12 @@ __global__ void rotate_emit_adjoint_kernel(const void* __restrict__ gout, const 
           wm[d] = (iok[a3] && jok[b3]) ? (wx * wy) * (mx * my) : 0.f;
           off[d] = base + rowo[a3] + colo[b3];
         }
-        const size_t cstride = is_patch<OUT>::v ? (size_t)patch * patch : (size_t)n * n;
+        const size_t cstride = (size_t)n * n;          // (planar layouts; the patch-major layouts hold a pixel's channels contiguously)
         float gv[9][3];
 #pragma unroll
         for (int d = 0; d < 9; ++d) {
-          gv[d][0] = gload<OUT>(gout, off[d]); gv[d][1] = gload<OUT>(gout, off[d] + cstride); gv[d][2] = gload<OUT>(gout, off[d] + 2 * cstride);
+          if (is_patch<OUT>::v) gload3<OUT>(gout, off[d], gv[d]);
+          else { gv[d][0] = gload<OUT>(gout, off[d]); gv[d][1] = gload<OUT>(gout, off[d] + cstride); gv[d][2] = gload<OUT>(gout, off[d] + 2 * cstride); }
         }
 #pragma unroll
         for (int d = 0; d < 9; ++d) { g0 += wm[d] * gv[d][0]; g1 += wm[d] * gv[d][1]; g2 += wm[d] * gv[d][2]; }

@@ -210,11 +210,9 @@ void launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (T <= AT_T)       // (the split dQ / dKdV kernels with NB = 1 were measured slower here: 7.62 vs 7.35 ms per C2 step)
   {
     if (T <= AT_RB)
-      APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse,
-                 a.dqkv, T, a.heads, items);
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items);
     else
-      APH_LAUNCH(attn_bwd_mfma_kernel<AT_T>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse,
-                 a.dqkv, T, a.heads, items);
+      APH_LAUNCH(attn_bwd_mfma_kernel<AT_T>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items);
   }
   else if (T <= 128) launch_attn_bwd_g<2>(a, st);
   else if (T <= 192) launch_attn_bwd_g<3>(a, st);
@@ -273,7 +271,16 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
   const std::string n(name);
   auto need = [&](size_t want) { return count == want ? 0 : aph_fail(APH_ERR_ARG, "aph_vit_set_weight(%s): %zu elements, expected %zu", name, count, want); };
   int rc = 0;
-  if (n == "conv1.weight") { if ((rc = need(D * Kp))) return rc; rc = upload_f16(v->w_patch, data, D, Kp, false) | upload_f16(v->w_patchT, data, D, Kp, true); }
+  if (n == "conv1.weight") {
+    if ((rc = need(D * Kp))) return rc;
+    // [D, 3, p, p] (openai/CLIP) -> K order of the sampler's patch rows: pixel-major, channel fastest (sampler.hip patch_index)
+    const size_t pp = (size_t)v->patch * v->patch;
+    std::vector<float> perm(D * Kp);
+    for (size_t d = 0; d < D; ++d)
+      for (size_t c = 0; c < 3; ++c)
+        for (size_t q = 0; q < pp; ++q) perm[d * Kp + q * 3 + c] = data[d * Kp + c * pp + q];
+    rc = upload_f16(v->w_patch, perm.data(), D, Kp, false) | upload_f16(v->w_patchT, perm.data(), D, Kp, true);
+  }
   else if (n == "class_embedding") { if ((rc = need(D))) return rc; rc = upload_f32(v->cls, data, 1, D, false); }
   else if (n == "positional_embedding") { if ((rc = need(T * D))) return rc; rc = upload_f32(v->pos, data, T, D, false); }
   else if (n == "ln_pre.weight") { if ((rc = need(D))) return rc; rc = upload_f32(v->ln_pre_g, data, 1, D, false); }

@@ -31,11 +31,14 @@ __device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((
 __device__ __forceinline__ void at_stage_load(const half_t* __restrict__ src, int ld, int T, int item, half8 (&rows)[8]) {
   const int c = item >> 3, sc = item & 7;
   const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);          // rows n(sc, i) = nbase + (i >> 2) * 16 + (i & 3)
+  // branch-free: rows >= T read the last valid row (T >= 1) and are zeroed by a select -- every lane issues all eight loads, so the
+  // compiler's vmcnt bookkeeping stays exact and no exec-mask branch sits between the loads
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n = nbase + ((i >> 2) << 4) + (i & 3);
     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    rows[i] = n < T ? *reinterpret_cast<const half8*>(src + (size_t)n * ld + c * 8) : z;
+    const half8 v = *reinterpret_cast<const half8*>(src + (size_t)(n < T ? n : T - 1) * ld + c * 8);
+    rows[i] = n < T ? v : z;
   }
 }
 __device__ __forceinline__ void at_stage_store(const half8 (&rows)[8], int item, half_t* rowmajor, half_t* transposed, int row_limit = 64) {
@@ -79,6 +82,38 @@ __device__ __forceinline__ half8 pack8(const f32x4& a, const f32x4& b) {
   return h;
 }
 
+// ---- softmax arithmetic, trimmed [r4] ---------------------------------------------------------------------------------------------
+// At T = 197 a lane holds 52 scores of its query and the blocked kernels are bound by the VALU work on them, not by memory or the matrix
+// pipe (persistent prefetching changed nothing: note further down).  Per score the round-3 code spent ~15 issue slots: scale, compare +
+// select (mask), max, subtract, multiply by log2 e, exp, compare + select again, add, convert.  Now:
+//   * the 1/8 scale and log2 e are ONE constant folded into the exponent's fma:  p = 2^(s * kSL - m * kSL)  (max taken on the raw scores);
+//   * only the LAST key tile of a row can hold keys >= T: the mask is applied there behind a wave-uniform branch, every full tile skips it,
+//     and a masked score of -1e30 needs no second select after the exponential (2^-huge = 0).
+constexpr float kSL = 0.125f * 1.4426950408889634f;      // scores / sqrt(64), in log2 units
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float fast_exp2(float x) {
+#ifdef APH_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+// raw scores of one 16-key tile starting at key t16 (this lane: keys t16 + g4 + r, r = 0..3): keys >= T -> -1e30 (a tile that reaches T
+// only: the test is wave-uniform), running max
+__device__ __forceinline__ void at_mask_max(f32x4& st, int t16, int g4, int T, float& mx) {
+  if (t16 + 15 >= T) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[r] = t16 + g4 + r < T ? st[r] : -1e30f;
+  }
+  mx = fmaxf(fmaxf(mx, fmaxf(st[0], st[1])), fmaxf(st[2], st[3]));
+}
+// Backward kernels: p = exp(s / 8 - L) recomputed from the raw scores, L2 = L * log2 e.  NO mask: the operand images are zero beyond row
+// T (staging zero-fills), so a key / query >= T contributes through a zero K^T / Q^T / dO^T row whatever p is -- as long as p and dS stay
+// finite in f16, which the clamp of the exponent at 0 guarantees (p <= 1; for a valid pair s / 8 <= L holds anyway, up to rounding).
+// One v_min instead of a compare + select per score, and no branch between the MFMAs (a wave-uniform "last tile only" branch inside the
+// unrolled product loops cost more than the selects it saved: 151 against 144 us at C4's shape).
+__device__ __forceinline__ float at_p(float s_raw, float L2) { return fast_exp2(fminf(fmaf(s_raw, kSL, -L2), 0.f)); }
+
 // qkv [M,3D] f16 -> att [M,D] f16, lse [S*heads*T] f32 (log-sum-exp of the scaled scores)
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att,
                                                            float* __restrict__ lse, int T, int heads) {
@@ -110,21 +145,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
   // lane: query i = it*16 + c16, keys j = jt*16 + g*4 + r
   float mx = -1e30f;
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = jt * 16 + g * 4 + r < T;
-      st[jt][r] = ok ? st[jt][r] * 0.125f : -1e30f;
-      mx = fmaxf(mx, st[jt][r]);
-    }
+  for (int jt = 0; jt < 4; ++jt) at_mask_max(st[jt], jt * 16, g * 4, T, mx);
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float mxs = mx * kSL;
   float l = 0.f;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] - mx) : 0.f;
+      const float p = fast_exp2(fmaf(st[jt][r], kSL, -mxs));       // (masked keys: 2^-huge = 0)
       st[jt][r] = p;
       l += p;
     }
@@ -140,18 +170,23 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
     o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, 4 + g), p1, o);
     if (i < T) store_h4(att + ((size_t)s * T + i) * D + h * 64 + dt * 16 + g * 4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
   }
-  if (g == 0 && i < T) lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
+  if (g == 0 && i < T) lse[((size_t)s * heads + h) * T + i] = mx * 0.125f + __logf(l);
 }
 
-// backward: (qkv, att, lse, datt) -> dqkv [M,3D] f16
+// backward: (qkv, lse, datt) -> dqkv [M,3D] f16   (`att` is not read: see D_i below)
 // PERSISTENT: the grid is a few workgroups per CU (3 fit its LDS), each walks the (cut, head) items with the grid stride.  The
 // operand rows of item i+1 are loaded into registers right after item i's have been written to LDS, so they are in flight
-// during item i's matrix products and stores: the kernel is HBM-bound (117 MB per launch at C2) and one item per workgroup
-// left the memory pipe idle during every compute phase (3.3 TB/s).
+// during item i's matrix products and stores: the kernel is HBM-bound and one item per workgroup left the memory pipe idle
+// during every compute phase (3.3 TB/s).
+// [r4] The softmax-gradient row term D_i = dO_i . O_i is formed as  sum_j P_ij dP_ij  (O = P V and dP = dO V^T, so the two are the
+// same sum) from the probabilities and dP phase A already holds in registers, instead of from a second read of dO plus a read of O:
+// 15 MB less HBM traffic per launch at C2 (117 -> 102 MB) and 16 fewer prefetch registers per lane.  The registers are what mattered:
+// at 170 VGPRs under a 168-register bound the compiler spilled one address pair, and its reload -- `scratch_load` + `s_waitcnt vmcnt(0)`,
+// vmcnt being one in-order counter -- sat right behind the prefetch loads of the next item: every wave waited for its prefetch to LAND
+// before starting the products the prefetch was meant to hide behind (found in the ISA; round 2's 35.7 -> 30.7 us was what survived).
 template <int RB>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
-__global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
-                                                           const half_t* __restrict__ datt, const float* __restrict__ lse,
-                                                           half_t* __restrict__ dqkv, int T, int heads, int items) {
+__global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ datt,
+                                                           const float* __restrict__ lse, half_t* __restrict__ dqkv, int T, int heads, int items) {
   constexpr int RT = RB * 64;                    // halfs per row-major tile
   __shared__ __attribute__((aligned(16))) half_t lds[4 * RT + 3 * 4096 + 256];
   half_t* Qs = lds;
@@ -165,120 +200,116 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
   float* Ds = Ls + 64;
   const int D = heads * 64, ld = 3 * D;
   const int which = wave_uniform(threadIdx.x >> 6), sitem = threadIdx.x & 63;       // staging role: wave `which` stages Q / K / V / dO
-  const int dr = threadIdx.x >> 2, dpart = threadIdx.x & 3;           // D_i = dO_i . O_i : 4 threads per row
   // prefetch registers of one item
-  half8 rows[8], ox[2], oy[2];
+  half8 rows[8];
   float lse_r = 0.f;
   auto fetch = [&](int item) {
     const int s = item / heads, h = item - s * heads;
     const half_t* base = qkv + (size_t)s * T * ld + h * 64;
     const half_t* dob = datt + (size_t)s * T * D + h * 64;
-    const half_t* ob = att + (size_t)s * T * D + h * 64;
     at_stage_load(which == 3 ? dob : base + which * D, which == 3 ? D : ld, T, sitem, rows);
-    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      ox[c] = dr < T ? *reinterpret_cast<const half8*>(ob + (size_t)dr * D + dpart * 16 + c * 8) : z;
-      oy[c] = dr < T ? *reinterpret_cast<const half8*>(dob + (size_t)dr * D + dpart * 16 + c * 8) : z;
-    }
-    lse_r = (dpart == 0 && dr < T) ? lse[((size_t)s * heads + h) * T + dr] : 0.f;
+    lse_r = (which == 0 && sitem < T) ? lse[(unsigned)(s * heads + h) * (unsigned)T + (unsigned)sitem] : 0.f;
   };
   int item = blockIdx.x;
   fetch(item);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  const bool active = w * 16 < T;
   for (;;) {
     const int s = item / heads, h = item - s * heads;
     // wave `which` = Q, K, V, dO: row-major tile `which`; transposed image for Q (0), K (1), dO (2) -- V has none
     at_stage_store(rows, sitem, lds + which * RT, which == 2 ? nullptr : lds + 4 * RT + (which == 3 ? 2 : which) * 4096, RB);
-    {
-      float a = 0.f;
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a += (float)ox[c][e] * (float)oy[c][e];
-      a += __shfl_xor(a, 1);
-      a += __shfl_xor(a, 2);
-      if (dpart == 0) {
-        Ds[dr] = a;
-        Ls[dr] = lse_r;
-      }
-    }
+    if (which == 0) Ls[sitem] = lse_r * kLog2e;
     __syncthreads();
     const int next = item + gridDim.x;
     if (next < items) fetch(next);               // in flight during the products and stores below
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
-  half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
-  if (w * 16 < T) {
-    // ---- phase A: wave = query tile.  S^T = K Q^T, dP^T = V dO^T (lane: query i, keys jt*16 + g*4 + r)
-    const int it = w, i = it * 16 + c16;
-    f32x4 st[4], dp[4];
+    half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+    if (active) {
+      // ---- phase A: wave = query tile.  S^T = K Q^T, dP^T = V dO^T (lane: query i, keys jt*16 + g*4 + r)
+      const int it = w, i = it * 16 + c16;
+      f32x4 st[4], dp[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) { st[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int jt = 0; jt < 4; ++jt) { st[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int kd = 0; kd < 2; ++kd) {
-      const half8 qf = at_frag_rows(Qs, i, kd * 4 + g, RB), of = at_frag_rows(Os, i, kd * 4 + g, RB);
+      for (int kd = 0; kd < 2; ++kd) {
+        const half8 qf = at_frag_rows(Qs, i, kd * 4 + g, RB), of = at_frag_rows(Os, i, kd * 4 + g, RB);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          st[jt] = mfma_16x16x32_f16(at_frag_rows(Ks, jt * 16 + c16, kd * 4 + g, RB), qf, st[jt]);
+          dp[jt] = mfma_16x16x32_f16(at_frag_rows(Vs, jt * 16 + c16, kd * 4 + g, RB), of, dp[jt]);
+        }
+      }
+      const float Li2 = Ls[i];                     // lse * log2 e
+      float Di = 0.f;                              // D_i = sum_j P_ij dP_ij (= dO_i . O_i): this lane's 16 keys, then the 4 key groups g
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        st[jt] = mfma_16x16x32_f16(at_frag_rows(Ks, jt * 16 + c16, kd * 4 + g, RB), qf, st[jt]);
-        dp[jt] = mfma_16x16x32_f16(at_frag_rows(Vs, jt * 16 + c16, kd * 4 + g, RB), of, dp[jt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[jt][r] = at_p(st[jt][r], Li2);         // (keys >= T: dP = 0 there -- V rows are zero -- so D_i does not see them)
+          Di += st[jt][r] * dp[jt][r];
+        }
       }
-    }
-    const float Li = Ls[i], Di = Ds[i];
+      Di += __shfl_xor(Di, 16);
+      Di += __shfl_xor(Di, 32);
+      if (g == 0) Ds[i] = Di;                      // for phase B (key tiles need the D of every query)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] * 0.125f - Li) : 0.f;
-        st[jt][r] = p * (dp[jt][r] - Di) * 0.125f;      // dS^T
+        for (int r = 0; r < 4; ++r) st[jt][r] = (st[jt][r] * 0.125f) * (dp[jt][r] - Di);      // dS^T
+      const half8 d0 = pack8(st[0], st[1]), d1 = pack8(st[2], st[3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, g), d0, o);
+        o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, 4 + g), d1, o);
+        if (i < T) store_h4(dbase + (size_t)i * ld + dt * 16 + g * 4, o[0], o[1], o[2], o[3]);
       }
-    const half8 d0 = pack8(st[0], st[1]), d1 = pack8(st[2], st[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, g), d0, o);
-      o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, 4 + g), d1, o);
-      if (i < T) store_h4(dbase + (size_t)i * ld + dt * 16 + g * 4, o[0], o[1], o[2], o[3]);
+    } else if (lane < 16) {
+      Ds[w * 16 + lane] = 0.f;                     // query tiles past T (their dO rows are zero)
     }
-    // ---- phase B: wave = key tile.  S = Q K^T, dP = dO V^T (lane: key j, queries it*16 + g*4 + r)
-    const int jt = w, j = jt * 16 + c16;
-    f32x4 sq[4], dq[4];
+    __syncthreads();                               // D of every query tile is in LDS
+    if (active) {
+      // ---- phase B: wave = key tile.  S = Q K^T, dP = dO V^T (lane: key j, queries it*16 + g*4 + r)
+      const int jt = w, j = jt * 16 + c16;
+      f32x4 sq[4], dq[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { sq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int t = 0; t < 4; ++t) { sq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int kd = 0; kd < 2; ++kd) {
-      const half8 kf = at_frag_rows(Ks, j, kd * 4 + g, RB), vf = at_frag_rows(Vs, j, kd * 4 + g, RB);
+      for (int kd = 0; kd < 2; ++kd) {
+        const half8 kf = at_frag_rows(Ks, j, kd * 4 + g, RB), vf = at_frag_rows(Vs, j, kd * 4 + g, RB);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sq[t] = mfma_16x16x32_f16(at_frag_rows(Qs, t * 16 + c16, kd * 4 + g, RB), kf, sq[t]);
+          dq[t] = mfma_16x16x32_f16(at_frag_rows(Os, t * 16 + c16, kd * 4 + g, RB), vf, dq[t]);
+        }
+      }
+      f32x4 pp[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        sq[t] = mfma_16x16x32_f16(at_frag_rows(Qs, t * 16 + c16, kd * 4 + g, RB), kf, sq[t]);
-        dq[t] = mfma_16x16x32_f16(at_frag_rows(Os, t * 16 + c16, kd * 4 + g, RB), vf, dq[t]);
+        const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + t * 16 + g * 4);      // (lse * log2 e)
+        const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (queries >= T: Q and dO rows are zero, L2 = D = 0 -> p = 1, dS = 0; their dO^T / Q^T rows are zero)
+          const float p = at_p(sq[t][r], L4[r]);
+          pp[t][r] = p;
+          sq[t][r] = (p * 0.125f) * (dq[t][r] - D4[r]);     // dS
+        }
+      }
+      const half8 p0 = pack8(pp[0], pp[1]), p1 = pack8(pp[2], pp[3]);
+      const half8 s0 = pack8(sq[0], sq[1]), s1 = pack8(sq[2], sq[3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
+        ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, g), p0, ov);
+        ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, 4 + g), p1, ov);
+        ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, g), s0, ok);
+        ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, 4 + g), s1, ok);
+        if (j < T) {
+          store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[0], ok[1], ok[2], ok[3]);
+          store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[0], ov[1], ov[2], ov[3]);
+        }
       }
     }
-    f32x4 pp[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + t * 16 + g * 4);
-      const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t * 16 + g * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = t * 16 + g * 4 + r < T ? __expf(sq[t][r] * 0.125f - L4[r]) : 0.f;
-        pp[t][r] = p;
-        sq[t][r] = p * (dq[t][r] - D4[r]) * 0.125f;     // dS
-      }
-    }
-    const half8 p0 = pack8(pp[0], pp[1]), p1 = pack8(pp[2], pp[3]);
-    const half8 s0 = pack8(sq[0], sq[1]), s1 = pack8(sq[2], sq[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
-      ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, g), p0, ov);
-      ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, 4 + g), p1, ov);
-      ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, g), s0, ok);
-      ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, 4 + g), s1, ok);
-      if (j < T) {
-        store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[0], ok[1], ok[2], ok[3]);
-        store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[0], ov[1], ov[2], ov[3]);
-      }
-    }
-  }
     if (next >= items) break;
     item = next;
     __syncthreads();                             // every wave is done with this item's LDS image
@@ -294,6 +325,11 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
 // stationary per wave, Q / dO fragments straight from global) and dK/dV with Q, dO, Q^T, dO^T resident (key tiles
 // stationary); both recompute P = exp(S/8 - lse) per 32-block from the saved log-sum-exp.
 // ---------------------------------------------------------------------------------------------------------------
+// (Round 4, measured and rejected: these three kernels as PERSISTENT workgroups with the next item's operand rows and the next tile round's
+// fragments prefetched into registers, like the one-tile backward above -- forward 70.0 us against 65.6, backward 137.9 against 143.9 at C4's
+// shape (profiles/r04_attn_bench.txt).  Nothing to hide: at T = 197 a lane holds 52 scores of its query and the softmax arithmetic on them --
+// scale, mask, max, subtract, exp, sum, convert: ~15 VALU slots per score, 2.6 k clocks per query tile next to 0.9 k of MFMA -- is what a
+// workgroup spends its time on; the static item split only added a 5-against-4.45 rounding.  git show <this commit>~1 has the code.)
 template <int NB>
 __device__ __forceinline__ void atg_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed, int idx) {
   const int blk = idx >> 6, item = idx & 63;
@@ -338,23 +374,22 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __re
     float mx = -1e30f;
 #pragma unroll
     for (int jt = 0; jt < 4 * NB; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = jt * 16 + g * 4 + r < T;
-        st[jt][r] = ok ? st[jt][r] * 0.125f : -1e30f;
-        mx = fmaxf(mx, st[jt][r]);
-      }
+      if (jt * 16 < T) at_mask_max(st[jt], jt * 16, g * 4, T, mx);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * kSL;
     float l = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 4 * NB; ++jt)
+    for (int jt = 0; jt < 4 * NB; ++jt) {
+      if (jt * 16 < T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = jt * 16 + g * 4 + r < T ? __expf(st[jt][r] - mx) : 0.f;
-        st[jt][r] = p;
-        l += p;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(fmaf(st[jt][r], kSL, -mxs));       // (masked keys: 2^-huge = 0)
+          st[jt][r] = p;
+          l += p;
+        }
+      }                                                                 // (tiles past T keep their zero: no MFMA ran on them)
+    }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __re
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         store_h4(att + ((size_t)s * T + i) * D + h * 64 + dt * 16 + g * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
-      if (g == 0) lse[((size_t)s * heads + h) * T + i] = mx + __logf(l);
+      if (g == 0) lse[((size_t)s * heads + h) * T + i] = mx * 0.125f + __logf(l);
     }
   }
 }
@@ -414,7 +449,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __rest
     }
     Di += __shfl_xor(Di, 16);
     Di += __shfl_xor(Di, 32);
-    const float Li = live ? lse[((size_t)s * heads + h) * T + i] : 0.f;
+    const float Li2 = live ? lse[((size_t)s * heads + h) * T + i] * kLog2e : 0.f;
     if (live && g == 0) delta[((size_t)s * heads + h) * T + i] = Di;
     f32x4 o[4];
 #pragma unroll
@@ -433,10 +468,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __rest
             dp[u] = mfma_16x16x32_f16(at_frag(Vs, jr, kd * 4 + g), of[kd], dp[u]);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = (2 * kb + u) * 16 + g * 4 + r < T ? __expf(st[u][r] * 0.125f - Li) : 0.f;
-            st[u][r] = p * (dp[u][r] - Di) * 0.125f;      // dS^T
-          }
+          for (int r = 0; r < 4; ++r) st[u][r] = (at_p(st[u][r], Li2) * 0.125f) * (dp[u][r] - Di);      // dS^T
         }
         const half8 df = pack8(st[0], st[1]);
 #pragma unroll
@@ -471,7 +503,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
     else atg_stage<NB>(dob, D, T, Os, Ot, idx - NB * 64);
   }
   for (int r = threadIdx.x; r < NB * 64; r += 512) {
-    Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] : 0.f;
+    Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] * kLog2e : 0.f;
     Ds[r] = r < T ? delta[((size_t)s * heads + h) * T + r] : 0.f;
   }
   __syncthreads();
@@ -506,9 +538,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
           const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t16 + g * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = t16 + g * 4 + r < T ? __expf(sq[u][r] * 0.125f - L4[r]) : 0.f;
+            const float p = at_p(sq[u][r], L4[r]);       // L4 = lse * log2 e
             pp[u][r] = p;
-            sq[u][r] = p * (dq[u][r] - D4[r]) * 0.125f;     // dS
+            sq[u][r] = (p * 0.125f) * (dq[u][r] - D4[r]);     // dS
           }
         }
         const half8 pf = pack8(pp[0], pp[1]), sf = pack8(sq[0], sq[1]);

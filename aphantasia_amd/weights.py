@@ -62,7 +62,16 @@ def synthetic_visual_weights(cfg, seed=1):
     w['ln_post.weight'] = torch.ones(width)
     w['ln_post.bias'] = torch.zeros(width)
     w['proj'] = scale * randn(width, cfg['output_dim'])
-    return w
+    return f16_representable(w)
+
+
+def f16_representable(w):
+    """OpenAI's archives store every tensor in fp16 ("Weights"); `clip.load` on a CPU up-casts those VALUES to fp32
+    (`model.float()`), the GPU path runs them as they are.  A synthetic stand-in is therefore rounded to f16-representable values too:
+    the fp32 CPU oracle and the f16 MFMA operands of the HIP path then see the SAME weights, as they would with a real checkpoint
+    (round 4: before, the f16 rounding of random fp32 weights was an error source of its own in every parity number -- the largest
+    single one in profiles/r04_precision_attribution.txt)."""
+    return {k: v.half().float() for k, v in w.items()}
 
 
 def load_openai_checkpoint(path):
@@ -126,4 +135,4 @@ def stress_visual_weights(cfg, seed=1):
     w['ln_post.weight'] = gn
     w['ln_post.bias'] = 0.1 * torch.randn(width, generator=g)
     w['proj'] = w['proj'] / gn[:, None] * 2.0
-    return w
+    return f16_representable(w)

@@ -116,7 +116,8 @@ typedef struct aph_sample_geom {
 
 #define APH_OUT_NCHW_RAW 0   /* f32 [S,3,size,size], no normalisation (transform=None) */
 #define APH_OUT_NCHW_NORM 1  /* f32 [S,3,size,size], CLIP mean/std normalised (transforms.normalize) */
-#define APH_OUT_PATCH_F16 2  /* f16 [S*(size/patch)^2, 3*patch*patch] normalised = patch-embed GEMM operand */
+#define APH_OUT_PATCH_F16 2  /* f16 [S*(size/patch)^2, 3*patch*patch] normalised = patch-embed GEMM operand; row = patch (s, gy, gx), column
+                              * k = (iy*patch + ix)*3 + c: pixel-major inside the patch, channel fastest (aph_vit_set_weight permutes conv1.weight to match) */
 #define APH_GRAD_PATCH_F16 3 /* aph_sample_bwd only: gradient in the patch-major layout stored as f16 (aph_vit_backward_h) */
 
 #define APH_AUG_STRIDE 16

@@ -19,10 +19,11 @@ def seed_all(s):
 
 
 def to_patch_major(x, p):
-    """[S,3,R,R] -> [S*g*g, 3*p*p] (the APH_OUT_PATCH_F16 element order)"""
+    """[S,3,R,R] -> [S*g*g, 3*p*p] (the APH_OUT_PATCH_F16 element order: patch (gy, gx), then pixel-major inside the patch with the
+    channel fastest -- k = (iy * p + ix) * 3 + c)"""
     S, _, Rr, _ = x.shape
     g = Rr // p
-    return x.reshape(S, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(S * g * g, 3 * p * p)
+    return x.reshape(S, 3, g, p, g, p).permute(0, 2, 4, 3, 5, 1).reshape(S * g * g, 3 * p * p)
 
 
 def check_synth_golden(lib, dev, g):

@@ -167,6 +167,8 @@ def test_attention_alone(emu):
     K.check_attention(emu, 'cpu', S=5, T=50, heads=2)       # 10 (cut, head) items on 3 persistent workgroups: 4 / 3 / 3 items each
     K.check_attention(emu, 'cpu', S=1, T=60, heads=1)       # one item, 64-row tiles
     K.check_attention(emu, 'cpu', S=2, T=82, heads=1)       # blocked kernels (T > 64)
+    K.check_attention(emu, 'cpu', S=4, T=70, heads=1)       # ... persistent: 4 items on 3 workgroups (one walks two items), one tile round
+    K.check_attention(emu, 'cpu', S=2, T=135, heads=2)      # ... three 64-token blocks: two tile rounds per wave (fragment sets A / B), ragged last tile
 
 
 def test_sampler_small_image_and_random_geometries(emu, monkeypatch):

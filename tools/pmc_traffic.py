@@ -2,6 +2,8 @@
 same bench.py command ->  profiles/<tag>_pmc_hbm_traffic.{csv,json}.
 
     python tools/pmc_traffic.py <fetch-dir> <write-dir> <steps-in-run> <tag> [workload note]
+    (a <tag> ending in `_c4` additionally sums the inverse-DWT kernels per pass: `irdwt_fwd_bytes_per_pass` / `irdwt_bwd_bytes_per_pass`,
+     tied to the sha256 of csrc/dwt.hip -- what bench.py --config c4 quotes as roofline.irdwt.traffic)
 
 Bytes per launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (FETCH_SIZE reads half of a wide coalesced stream on gfx950:
 MI355X_MICROARCH.md, HBM section; WRITE_SIZE as reported, uncalibrated).  The json carries the sha256 of the library that
@@ -55,6 +57,13 @@ def main():
                lib_sha256=hashlib.sha256(open(lib, 'rb').read()).hexdigest(), gemm_src_sha256=gemm_src_sha(), workload=note,
                source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the same bench.py command; FETCH_SIZE doubled '
                       '(gfx950 half-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported')
+    if tag.endswith('_c4'):
+        from bench import dwt_src_sha
+        fwd = sum(r[5] * 1e6 * r[1] for r in rows if 'idwt_' in r[0] and 'adjoint' not in r[0]) / steps
+        bwd = sum(r[5] * 1e6 * r[1] for r in rows if 'idwt_' in r[0] and 'adjoint' in r[0]) / steps
+        out.update(irdwt_fwd_bytes_per_pass=fwd, irdwt_bwd_bytes_per_pass=bwd, dwt_src_sha256=dwt_src_sha(),
+                   irdwt_note='sum over idwt_level_kernel + idwt_coarse_kernel (forward) / their adjoints of 2 x FETCH_SIZE + WRITE_SIZE, per optimisation step (one pass each way)')
+        print('irDWT: forward %.1f MB / pass, adjoint %.1f MB / pass' % (fwd / 1e6, bwd / 1e6))
     with open(os.path.join(ROOT, 'profiles', tag + '_pmc_hbm_traffic.json'), 'w') as f:
         json.dump(out, f, indent=1)
     for r in rows[:14]:
