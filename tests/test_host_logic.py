@@ -254,7 +254,9 @@ def test_bench_traffic_summary_matching(tmp_path, monkeypatch):
     write('r04_pmc_hbm_traffic.json', lib_sha256='L' * 64)
     t, src, stale, match = bench.pmc_traffic('r*_pmc_hbm_traffic*.json')
     assert (os.path.basename(src), stale, match) == ('r04_pmc_hbm_traffic.json', False, 'library')
-    # the committed round-3 summary matches this checkout's GEMM sources (the GEMM kernels have not changed since it was taken)
+    # the committed round-4 summaries match this checkout's sources (ViT translation unit / csrc/dwt.hip unchanged since they were taken)
     monkeypatch.undo()
-    real = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')))
+    real = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r04_pmc_hbm_traffic.json')))
     assert real['gemm_src_sha256'] == bench.gemm_src_sha()
+    real4 = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r04_c4_pmc_hbm_traffic.json')))
+    assert real4['dwt_src_sha256'] == bench.dwt_src_sha() and real4['irdwt_fwd_bytes_per_pass'] > 2.6e8
