@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libaphantasia_hip.so')
 
-APH_OUT_NCHW_RAW, APH_OUT_NCHW_NORM, APH_OUT_PATCH_F16, APH_GRAD_PATCH_F16 = 0, 1, 2, 3
+APH_OUT_NCHW_RAW, APH_OUT_NCHW_NORM, APH_OUT_PATCH_F16, APH_GRAD_PATCH_F16, APH_OUT_PATCH_F16_HILO = 0, 1, 2, 3, 4
 APH_AUG_STRIDE = 16
 SIM_TYPES = {'cossim': 0, 'cos': 0, None: 0, 'mix': 1, 'ang': 2, 'dot': 3}
 
@@ -56,12 +56,14 @@ _PROTOTYPES = {
     'aph_attn_test': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'aph_frame_affine': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
     'aph_patchify_f16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'aph_patchify_f16_hilo': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'aph_unpatchify_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'aph_vit_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     'aph_vit_destroy': (c_int, [c_void_p]),
     'aph_vit_workspace_bytes': (c_size_t, [c_void_p]),
     'aph_vit_set_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     'aph_vit_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'aph_vit_forward_hilo': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_vit_backward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     'aph_vit_backward_h': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     'aph_vit_profile': (c_int, [c_void_p, c_int]),

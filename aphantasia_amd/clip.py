@@ -60,10 +60,10 @@ class VisualTransformer:
         if S > self.handle.max_batch:
             self.handle = ops.VitHandle(self.cfg, self.weights, S, lib=self.lib)
 
-    def _forward_patches(self, patches, S, out=None):
+    def _forward_patches(self, patches, S, out=None, hilo=False):
         self.ensure_batch(S)
         self._generation += 1
-        return self.handle.forward(patches, S, out)
+        return self.handle.forward(patches, S, out, hilo=hilo)
 
     def __call__(self, x):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.input_resolution or x.shape[3] != self.input_resolution:

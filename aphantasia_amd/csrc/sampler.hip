@@ -141,6 +141,16 @@ __device__ __forceinline__ void emit3(void* out, int s, int i, int j, int size, 
     q[0] = (half_t)((v0 - kClipMean[0]) / kClipStd[0]);
     q[1] = (half_t)((v1 - kClipMean[1]) / kClipStd[1]);
     q[2] = (half_t)((v2 - kClipMean[2]) / kClipStd[2]);
+  } else if (OUT == APH_OUT_PATCH_F16_HILO) {
+    // rows [hi (Kp) | lo (Kp)]: hi = f16(x), lo = f16(x - hi) -- the A operand of the split-precision patch embedding (aph_vit_forward_hilo)
+    const int kp = 3 * patch * patch;
+    const size_t o = patch_index(s, 0, i, j, size, patch);
+    const size_t row = o / (size_t)kp;
+    half_t* q = reinterpret_cast<half_t*>(out) + o + row * (size_t)kp;
+    const float n0 = (v0 - kClipMean[0]) / kClipStd[0], n1 = (v1 - kClipMean[1]) / kClipStd[1], n2 = (v2 - kClipMean[2]) / kClipStd[2];
+    const half_t h0 = (half_t)n0, h1 = (half_t)n1, h2 = (half_t)n2;
+    q[0] = h0; q[1] = h1; q[2] = h2;
+    q[kp] = (half_t)(n0 - (float)h0); q[kp + 1] = (half_t)(n1 - (float)h1); q[kp + 2] = (half_t)(n2 - (float)h2);
   } else {
     emit<OUT>(out, s, 0, i, j, size, patch, v0);
     emit<OUT>(out, s, 1, i, j, size, patch, v1);
@@ -1064,11 +1074,17 @@ __global__ void frame_affine_kernel(const float* __restrict__ src, float* __rest
 // ---------------------------------------------------------------------------------
 // layout conversion for caller-made batches (model.encode_image(x) on an NCHW tensor)
 // ---------------------------------------------------------------------------------
-__global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int S, int R, int p) {
+__global__ void patchify_kernel(const float* __restrict__ x, half_t* __restrict__ out, int S, int R, int p, int hilo) {
   const size_t n = (size_t)S * 3 * R * R;
+  const size_t kp = (size_t)3 * p * p;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
     const int j = idx % R, i = (idx / R) % R, c = (idx / ((size_t)R * R)) % 3, s = idx / ((size_t)3 * R * R);
-    out[patch_index(s, c, i, j, R, p)] = (half_t)x[idx];
+    const size_t o = patch_index(s, c, i, j, R, p);
+    const half_t h = (half_t)x[idx];
+    if (!hilo) { out[o] = h; continue; }
+    const size_t q = o + (o / kp) * kp;                       // rows [hi | lo]
+    out[q] = h;
+    out[q + kp] = (half_t)(x[idx] - (float)h);
   }
 }
 __global__ void unpatchify_kernel(const float* __restrict__ g, float* __restrict__ out, int S, int R, int p, float gscale) {
@@ -1087,9 +1103,11 @@ static Geom to_geom(const aph_sample_geom* g) { return Geom{g->H, g->W, g->Hp, g
 
 static int check_geom(const aph_sample_geom* g, int out_mode, const char* who, int max_mode = 2) {
   if (!g) return aph_fail(APH_ERR_ARG, "%s: null geometry", who);
+  if (out_mode == APH_OUT_PATCH_F16_HILO && max_mode == 2) max_mode = APH_OUT_PATCH_F16_HILO;      // forward only: the split-precision patch rows
   if (g->S < 1 || g->size < 1 || g->H < 1 || g->W < 1 || g->Hp < g->H || g->Wp < g->W)
     return aph_fail(APH_ERR_ARG, "%s: bad geometry S=%d size=%d H=%d W=%d Hp=%d Wp=%d", who, g->S, g->size, g->H, g->W, g->Hp, g->Wp);
-  if (out_mode < 0 || out_mode > max_mode) return aph_fail(APH_ERR_ARG, "%s: bad out_mode %d", who, out_mode);
+  if (out_mode < 0 || out_mode > max_mode || (out_mode == APH_GRAD_PATCH_F16 && max_mode != APH_GRAD_PATCH_F16))
+    return aph_fail(APH_ERR_ARG, "%s: bad out_mode %d", who, out_mode);
   if (out_mode >= APH_OUT_PATCH_F16 && (g->patch < 1 || g->size % g->patch || (g->patch & (g->patch - 1))))
     return aph_fail(APH_ERR_ARG, "%s: size %d not divisible by patch %d, or patch not a power of two", who, g->size, g->patch);
   return APH_OK;
@@ -1193,7 +1211,8 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   if (!aug) {
     if (out_mode == APH_OUT_NCHW_RAW) launch_crop_resize<APH_OUT_NCHW_RAW>(rgb, (const int*)table, out, g, ws, st);
     else if (out_mode == APH_OUT_NCHW_NORM) launch_crop_resize<APH_OUT_NCHW_NORM>(rgb, (const int*)table, out, g, ws, st);
-    else launch_crop_resize<APH_OUT_PATCH_F16>(rgb, (const int*)table, out, g, ws, st);
+    else if (out_mode == APH_OUT_PATCH_F16) launch_crop_resize<APH_OUT_PATCH_F16>(rgb, (const int*)table, out, g, ws, st);
+    else launch_crop_resize<APH_OUT_PATCH_F16_HILO>(rgb, (const int*)table, out, g, ws, st);
     return aph_check_launch("aph_sample_fwd");
   }
   float* A = reinterpret_cast<float*>(static_cast<char*>(ws) + tab_bytes(g) + strip_bytes(g));
@@ -1203,7 +1222,8 @@ int aph_sample_fwd(const aph_sample_geom* gg, const float* rgb, const int32_t* t
   APH_LAUNCH(persp_kernel, grid, block, 0, st, (const float*)A, aug, Bv, n);
   if (out_mode == APH_OUT_NCHW_RAW) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_RAW>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
   else if (out_mode == APH_OUT_NCHW_NORM) APH_LAUNCH(rotate_emit_kernel<APH_OUT_NCHW_NORM>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
-  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
+  else if (out_mode == APH_OUT_PATCH_F16) APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
+  else APH_LAUNCH(rotate_emit_kernel<APH_OUT_PATCH_F16_HILO>, grid, block, 0, st, (const float*)A, (const float*)Bv, aug, out, n, g.patch);
   return aph_check_launch("aph_sample_fwd");
   APH_CATCH
 }
@@ -1243,8 +1263,17 @@ int aph_sample_bwd(const aph_sample_geom* gg, const void* gout, float gscale, co
 int aph_patchify_f16(const float* x, int S, int R, int patch, void* out, void* stream_) {
   APH_TRY
   if (!x || !out || S < 1 || R < 1 || patch < 1 || R % patch) return aph_fail(APH_ERR_ARG, "aph_patchify_f16: bad argument");
-  APH_LAUNCH(patchify_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, x, (half_t*)out, S, R, patch);
+  APH_LAUNCH(patchify_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, x, (half_t*)out, S, R, patch, 0);
   return aph_check_launch("aph_patchify_f16");
+  APH_CATCH
+}
+
+// the same into the split-precision rows [hi | lo] of aph_vit_forward_hilo: out f16 [S*(R/patch)^2, 2 * 3*patch*patch]
+int aph_patchify_f16_hilo(const float* x, int S, int R, int patch, void* out, void* stream_) {
+  APH_TRY
+  if (!x || !out || S < 1 || R < 1 || patch < 1 || R % patch) return aph_fail(APH_ERR_ARG, "aph_patchify_f16_hilo: bad argument");
+  APH_LAUNCH(patchify_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream_, x, (half_t*)out, S, R, patch, 1);
+  return aph_check_launch("aph_patchify_f16_hilo");
   APH_CATCH
 }
 

@@ -21,6 +21,7 @@ namespace {
 
 struct Layer {
   half_t *w_qkv = nullptr, *w_qkvT = nullptr, *w_o = nullptr, *w_oT = nullptr;
+  half_t* w_qkv2 = nullptr;            // [3D, 2D]: w_qkv repeated along K (split-precision forward)
   half_t *w_fc1 = nullptr, *w_fc1T = nullptr, *w_fc2 = nullptr, *w_fc2T = nullptr;
   float *b_qkv = nullptr, *b_o = nullptr, *b_fc1 = nullptr, *b_fc2 = nullptr;
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
@@ -33,7 +34,7 @@ struct Layer {
 
 struct aph_vit {
   int res, patch, D, L, heads, E, T, P, Kp, max_batch;
-  half_t *w_patch = nullptr, *w_patchT = nullptr;
+  half_t *w_patch = nullptr, *w_patchT = nullptr, *w_patch2 = nullptr;      // w_patch2 [D, 2 Kp]: w_patch repeated along K
   float *cls = nullptr, *pos = nullptr, *ln_pre_g = nullptr, *ln_pre_b = nullptr, *ln_post_g = nullptr, *ln_post_b = nullptr;
   float *proj = nullptr, *projT = nullptr;
   std::vector<Layer> layers;
@@ -67,13 +68,13 @@ struct Carver {
 void carve(aph_vit* v, char* base, size_t* total) {
   Carver c{base};
   const size_t D = v->D, Mx = (size_t)v->max_batch * v->T, E = v->E, Kp = v->Kp, T = v->T;
-  v->w_patch = c.take<half_t>(D * Kp); v->w_patchT = c.take<half_t>(D * Kp);
+  v->w_patch = c.take<half_t>(D * Kp); v->w_patchT = c.take<half_t>(D * Kp); v->w_patch2 = c.take<half_t>(2 * D * Kp);
   v->cls = c.take<float>(D); v->pos = c.take<float>(T * D);
   v->ln_pre_g = c.take<float>(D); v->ln_pre_b = c.take<float>(D);
   v->ln_post_g = c.take<float>(D); v->ln_post_b = c.take<float>(D);
   v->proj = c.take<float>(D * E); v->projT = c.take<float>(D * E);
   for (auto& l : v->layers) {
-    l.w_qkv = c.take<half_t>(3 * D * D); l.w_qkvT = c.take<half_t>(3 * D * D);
+    l.w_qkv = c.take<half_t>(3 * D * D); l.w_qkvT = c.take<half_t>(3 * D * D); l.w_qkv2 = c.take<half_t>(6 * D * D);
     l.w_o = c.take<half_t>(D * D); l.w_oT = c.take<half_t>(D * D);
     l.w_fc1 = c.take<half_t>(4 * D * D); l.w_fc1T = c.take<half_t>(4 * D * D);
     l.w_fc2 = c.take<half_t>(4 * D * D); l.w_fc2T = c.take<half_t>(4 * D * D);
@@ -83,7 +84,7 @@ void carve(aph_vit* v, char* base, size_t* total) {
     l.qkv = c.take<half_t>(Mx * 3 * D); l.att = c.take<half_t>(Mx * D); l.u = c.take<half_t>(Mx * 4 * D);
   }
   v->x0 = c.take<float>(Mx * D); v->x_last = c.take<float>(Mx * D);
-  v->h = c.take<half_t>(Mx * D); v->gact = c.take<half_t>(Mx * 4 * D);
+  v->h = c.take<half_t>(Mx * 2 * D); v->gact = c.take<half_t>(Mx * 4 * D);      // h: [hi | lo] rows in the split-precision forward
   v->dx = c.take<float>(Mx * D);
   v->delta = c.take<float>((size_t)v->max_batch * v->heads * T);
   v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
@@ -102,6 +103,13 @@ int upload_f16(half_t* dst, const float* src, size_t rows, size_t cols, bool tra
     for (size_t r = 0; r < rows; ++r)
       for (size_t c = 0; c < cols; ++c) tmp[c * rows + r] = (half_t)src[r * cols + c];
   }
+  return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+// host fp32 [rows, cols] -> device fp16 [rows, 2 cols]: every row twice along K (the B operand of a hi | lo split GEMM)
+int upload_f16_twice(half_t* dst, const float* src, size_t rows, size_t cols) {
+  std::vector<half_t> tmp(rows * cols * 2);
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < cols; ++c) tmp[r * 2 * cols + c] = tmp[r * 2 * cols + cols + c] = (half_t)src[r * cols + c];
   return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 int upload_f32(float* dst, const float* src, size_t rows, size_t cols, bool transpose) {
@@ -131,13 +139,13 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
 template <bool OUT_F16, bool CLS>
 void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void* out, int M, int T, const float* cls,
                    const float* pos, float* x_fill, hipStream_t st, int xs = 1, const float* g2 = nullptr, const float* b2 = nullptr,
-                   half_t* out2 = nullptr) {
+                   half_t* out2 = nullptr, int hilo = 0) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
-    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
-    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
-    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2); break;
+    case 1: APH_LAUNCH((ln_fwd_kernel<1, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2, hilo); break;
+    case 2: APH_LAUNCH((ln_fwd_kernel<2, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2, hilo); break;
+    case 3: APH_LAUNCH((ln_fwd_kernel<3, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2, hilo); break;
+    default: APH_LAUNCH((ln_fwd_kernel<4, OUT_F16, CLS>), grid, block, 0, st, x, g, b, out, M, T, cls, pos, x_fill, xs, g2, b2, out2, hilo); break;
   }
 }
 // res_T: residual on the rows with row % res_T == 0 only;  x_b / g_b: the previous LayerNorm's backward fused behind this one (ln_bwd_kernel)
@@ -279,7 +287,7 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
     for (size_t d = 0; d < D; ++d)
       for (size_t c = 0; c < 3; ++c)
         for (size_t q = 0; q < pp; ++q) perm[d * Kp + q * 3 + c] = data[d * Kp + c * pp + q];
-    rc = upload_f16(v->w_patch, perm.data(), D, Kp, false) | upload_f16(v->w_patchT, perm.data(), D, Kp, true);
+    rc = upload_f16(v->w_patch, perm.data(), D, Kp, false) | upload_f16(v->w_patchT, perm.data(), D, Kp, true) | upload_f16_twice(v->w_patch2, perm.data(), D, Kp);
   }
   else if (n == "class_embedding") { if ((rc = need(D))) return rc; rc = upload_f32(v->cls, data, 1, D, false); }
   else if (n == "positional_embedding") { if ((rc = need(T * D))) return rc; rc = upload_f32(v->pos, data, T, D, false); }
@@ -296,7 +304,7 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
     if (li < 0 || li >= v->L) return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: layer %d out of range", li);
     Layer& l = v->layers[li];
     const std::string k = n.substr(dot + 1);
-    if (k == "attn.in_proj_weight") { if ((rc = need(3 * D * D))) return rc; rc = upload_f16(l.w_qkv, data, 3 * D, D, false) | upload_f16(l.w_qkvT, data, 3 * D, D, true); }
+    if (k == "attn.in_proj_weight") { if ((rc = need(3 * D * D))) return rc; rc = upload_f16(l.w_qkv, data, 3 * D, D, false) | upload_f16(l.w_qkvT, data, 3 * D, D, true) | upload_f16_twice(l.w_qkv2, data, 3 * D, D); }
     else if (k == "attn.in_proj_bias") { if ((rc = need(3 * D))) return rc; rc = upload_f32(l.b_qkv, data, 1, 3 * D, false); }
     else if (k == "attn.out_proj.weight") { if ((rc = need(D * D))) return rc; rc = upload_f16(l.w_o, data, D, D, false) | upload_f16(l.w_oT, data, D, D, true); }
     else if (k == "attn.out_proj.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.b_o, data, 1, D, false); }
@@ -317,22 +325,26 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
 }
 
 // encode_image: d_patches f16 [S*P, 3*patch*patch] (patch-major, CLIP-normalised) -> d_enc f32 [S, output_dim]
-int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void* stream_) {
-  APH_TRY
+// hilo: the SPLIT-PRECISION forward -- d_patches rows are [hi (Kp) | lo (Kp)] (APH_OUT_PATCH_F16_HILO) and the first LayerNorm of every
+// block writes [hi (D) | lo (D)]: the patch-embedding and the QKV GEMMs then run over K = 2 Kp / 2 D against the weights repeated along K,
+// i.e. with ~22 operand bits on the two activations whose f16 rounding dominates the input-gradient error on weights with realistic
+// dynamic range (profiles/r04_precision_attribution.txt).  Everything else, the backward included, is unchanged.
+static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_enc, bool hilo, void* stream_) {
   if (!v || !d_patches || !d_enc) return aph_fail(APH_ERR_ARG, "aph_vit_forward: null argument");
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_forward: batch %d outside 1..%d", S, v->max_batch);
   if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_forward: weights not fully loaded (%d tensors)", v->n_set);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
-  vgemm(v, (const half_t*)d_patches, v->Kp, v->w_patch, v->Kp, S * v->P, D, v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
+  const int kx = hilo ? 2 : 1;
+  vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
   const bool fuse = g_fuse_ln != 0;
   launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st, 1,
-                             fuse ? v->layers[0].ln1_g : nullptr, fuse ? v->layers[0].ln1_b : nullptr, fuse ? v->h : nullptr);
+                             fuse ? v->layers[0].ln1_g : nullptr, fuse ? v->layers[0].ln1_b : nullptr, fuse ? v->h : nullptr, hilo ? 1 : 0);
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
-    if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st);
-    vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+    if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
+    vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
     launch_attn_fwd(attn_args(v, l, S), st);
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
     // its attention runs on the S class rows alone: the same buffers addressed with a row pitch of T rows.
@@ -346,6 +358,16 @@ int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void
   APH_LAUNCH(head_fwd_kernel, dim3(S, (v->E + 127) / 128), dim3(256), sizeof(float) * (D + 256), st, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
   return aph_check_launch("aph_vit_forward");
+}
+int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void* stream_) {
+  APH_TRY
+  return vit_forward_impl(v, d_patches, S, d_enc, false, stream_);
+  APH_CATCH
+}
+// d_patches_hilo f16 [S*P, 2 * 3*patch*patch] (APH_OUT_PATCH_F16_HILO rows [hi | lo])
+int aph_vit_forward_hilo(aph_vit* v, const void* d_patches_hilo, int S, float* d_enc, void* stream_) {
+  APH_TRY
+  return vit_forward_impl(v, d_patches_hilo, S, d_enc, true, stream_);
   APH_CATCH
 }
 

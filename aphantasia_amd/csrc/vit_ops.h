@@ -24,7 +24,9 @@ template <int NV, bool OUT_F16, bool CLS_FILL>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                               void* __restrict__ out, int M, int T, const float* __restrict__ cls, const float* __restrict__ pos,
                               float* __restrict__ x_fill, int xs, const float* __restrict__ gamma2 = nullptr,
-                              const float* __restrict__ beta2 = nullptr, half_t* __restrict__ out2 = nullptr) {
+                              const float* __restrict__ beta2 = nullptr, half_t* __restrict__ out2 = nullptr, int hilo = 0) {
+  // hilo (f16 outputs only; the split-precision forward, aph_vit_forward_hilo): a row is written as [hi (D) | lo (D)] with
+  // hi = f16(y), lo = f16(y - hi): the A operand of a GEMM over K = 2 D against the weights repeated along K
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -60,7 +62,12 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
     for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
     if (OUT_F16) {
       half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-      *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(out) + (size_t)row * D + d) = h;
+      half_t* op = reinterpret_cast<half_t*>(out) + (size_t)row * (hilo ? 2 * D : D) + d;
+      *reinterpret_cast<half4*>(op) = h;
+      if (hilo) {
+        half4 l = {(half_t)(o[0] - (float)h[0]), (half_t)(o[1] - (float)h[1]), (half_t)(o[2] - (float)h[2]), (half_t)(o[3] - (float)h[3])};
+        *reinterpret_cast<half4*>(op + D) = l;
+      }
     } else {
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)row * D + d) = o;
       v[i] = o;
@@ -85,7 +92,12 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean2) * rstd2 * g[j] + b[j];
       half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-      *reinterpret_cast<half4*>(out2 + (size_t)row * D + d) = h;
+      half_t* op = out2 + (size_t)row * (hilo ? 2 * D : D) + d;
+      *reinterpret_cast<half4*>(op) = h;
+      if (hilo) {
+        half4 l = {(half_t)(o[0] - (float)h[0]), (half_t)(o[1] - (float)h[1]), (half_t)(o[2] - (float)h[2]), (half_t)(o[3] - (float)h[3])};
+        *reinterpret_cast<half4*>(op + D) = l;
+      }
     }
   }
 }

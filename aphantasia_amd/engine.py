@@ -37,14 +37,17 @@ class Engine:
     def __init__(self, params, h, w, model, samples, targets, sim='mix', colors=1.8, decay=1.5,
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, comm=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
-                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False, aest=None):
+                 rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False, aest=None,
+                 precise=False):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
         coef = sign*weight as at clip_fft.py:257-267.
         rng: 'bulk' = vectorised host draws from a numpy Generator seeded off torch's global generator (same
         distributions, ~0.1 ms/step); 'reference' = the reference's exact per-cut draw order on torch's / numpy's
-        global generators (a seeded run then reproduces the reference's crop tables; costs milliseconds of Python)."""
+        global generators (a seeded run then reproduces the reference's crop tables; costs milliseconds of Python).
+        precise: the opt-in split-precision ViT forward (aph_vit_forward_hilo: the cuts and every block's first LayerNorm output as hi + lo
+        f16 pairs -- the two roundings that dominate the gradient error on weights with realistic dynamic range; ~8 % slower at C2)."""
         self.params = params
         self.dev = params.device
         self.h, self.w = h, w
@@ -128,7 +131,9 @@ class Engine:
         Sl = max(self.S_loc, 1)
         self.raw = torch.empty(3, h, w, **f32)
         self.rgb = torch.empty(3, h, w, **f32)
-        self.patches = torch.empty(Sl * self.P, self.Kp, dtype=torch.float16, device=self.dev)
+        self.precise = bool(precise)
+        self._patch_mode = _ffi.APH_OUT_PATCH_F16_HILO if self.precise else _ffi.APH_OUT_PATCH_F16
+        self.patches = torch.empty(Sl * self.P, (2 if self.precise else 1) * self.Kp, dtype=torch.float16, device=self.dev)
         # ViT input-gradient handed to the sampler adjoint: f32 (default, exact path) or f16 carrying the loss scale
         # (measured: -1.6 % step time at C2, 5e-4 relative rounding per gradient element)
         self.grad_f16 = bool(grad_f16)
@@ -263,8 +268,8 @@ class Engine:
         vit_scale, smp_scale, gmode = self._grad_modes()
         if Sl > 0:
             L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table), ops.ptr(self.aug), ops.ptr(self.tmp),
-                   ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
-            self.visual._forward_patches(self.patches, Sl, self.enc)
+                   ops.ptr(self.patches), self._patch_mode, st)
+            self.visual._forward_patches(self.patches, Sl, self.enc, hilo=self.precise)
             L.call('aph_sim_loss', ops.ptr(self.enc), Sl, self.enc.shape[1], ops.ptr(self.targets), ops.ptr(self.dcoef), self.hcoef,
                    len(self.coef), self.n_broadcast, self.S, self.lo, _ffi.SIM_TYPES[ops._sim_key(self.sim)], float(self.S), self.loss_scale, ops.ptr(self.ws),
                    ops.ptr(self.loss), ops.ptr(self.genc), st)
@@ -318,8 +323,8 @@ class Engine:
             L.call('aph_sim_loss', ops.ptr(enc), Sl, D, ops.ptr(other), ops.ptr(self.enf_coef), hc, 1, 0, Sl, 0, code, float(self.S),
                    self.loss_scale, ops.ptr(self.ws2), ops.ptr(loss), ops.ptr(genc), st)
         L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table2), ops.ptr(self.aug2), ops.ptr(self.tmp),
-               ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
-        self.visual._forward_patches(self.patches, Sl, self.enc2)
+               ops.ptr(self.patches), self._patch_mode, st)
+        self.visual._forward_patches(self.patches, Sl, self.enc2, hilo=self.precise)
         pair_term(self.enc2, self.enc, self.loss2, self.genc2)
         vit_scale, smp_scale, gmode = self._grad_modes()
         self.visual.handle.backward(self.genc2, Sl, self.gpatch, vit_scale)
@@ -328,8 +333,8 @@ class Engine:
         pair_term(self.enc, self.enc2, self.loss2, self.genc2)       # same value again; genc2 now = d/d enc (first set)
         L.call('aph_axpy_f32', ops.ptr(self.genc), ops.ptr(self.genc2), 1.0, self.genc.numel(), st)
         L.call('aph_sample_fwd', ctypes_byref(self.geom), ops.ptr(self.rgb), ops.ptr(self.table), ops.ptr(self.aug), ops.ptr(self.tmp),
-               ops.ptr(self.patches), _ffi.APH_OUT_PATCH_F16, st)
-        self.visual._forward_patches(self.patches, Sl, self.enc)
+               ops.ptr(self.patches), self._patch_mode, st)
+        self.visual._forward_patches(self.patches, Sl, self.enc, hilo=self.precise)
 
     def _stepin_views(self, flat):
         return {name: flat[o:o + n].view(dt).view(shape) for name, o, n, shape, dt in self._stepin_layout}

@@ -132,9 +132,10 @@ def make_geom(H, W, S, size, patch=32, align='uniform'):
 
 
 def sample_out_shape(geom, out_mode):
-    if out_mode == _ffi.APH_OUT_PATCH_F16:
+    if out_mode in (_ffi.APH_OUT_PATCH_F16, _ffi.APH_OUT_PATCH_F16_HILO):
         g = geom.size // geom.patch
-        return (geom.S * g * g, 3 * geom.patch * geom.patch), torch.float16
+        kx = 2 if out_mode == _ffi.APH_OUT_PATCH_F16_HILO else 1           # rows [hi | lo] of the split-precision forward
+        return (geom.S * g * g, kx * 3 * geom.patch * geom.patch), torch.float16
     return (geom.S, 3, geom.size, geom.size), torch.float32
 
 
@@ -170,13 +171,14 @@ def sample_bwd(geom, gout, table, aug=None, tmp=None, out=None, out_mode=_ffi.AP
     return out
 
 
-def patchify(x, patch, lib=None):
+def patchify(x, patch, lib=None, hilo=False):
+    """NCHW f32 -> the patch-embed GEMM operand; hilo: rows [hi | lo] for VitHandle.forward(..., hilo=True)"""
     L = _L(lib, x)
     _chk(x, torch.float32, 'x')
     S, _, R, _ = x.shape
     g = R // patch
-    out = torch.empty(S * g * g, 3 * patch * patch, dtype=torch.float16, device=x.device)
-    L.call('aph_patchify_f16', ptr(x), S, R, patch, ptr(out), _stream(x))
+    out = torch.empty(S * g * g, (2 if hilo else 1) * 3 * patch * patch, dtype=torch.float16, device=x.device)
+    L.call('aph_patchify_f16_hilo' if hilo else 'aph_patchify_f16', ptr(x), S, R, patch, ptr(out), _stream(x))
     return out
 
 
@@ -209,10 +211,14 @@ class VitHandle:
     def workspace_bytes(self):
         return int(self.lib.cdll.aph_vit_workspace_bytes(self.handle))
 
-    def forward(self, patches, S, out=None):
+    def forward(self, patches, S, out=None, hilo=False):
+        """hilo: the opt-in split-precision forward (aph_vit_forward_hilo); `patches` then holds [hi | lo] rows (APH_OUT_PATCH_F16_HILO)"""
         if out is None:
             out = torch.empty(S, self.cfg['output_dim'], dtype=torch.float32, device=patches.device)
-        self.lib.call('aph_vit_forward', self.handle, ptr(patches), int(S), ptr(out), _stream(patches))
+        want = (2 if hilo else 1) * self.Kp
+        if patches.shape[-1] != want:
+            raise ValueError('VitHandle.forward(hilo=%s): patch rows of %d halfs, expected %d' % (hilo, patches.shape[-1], want))
+        self.lib.call('aph_vit_forward_hilo' if hilo else 'aph_vit_forward', self.handle, ptr(patches), int(S), ptr(out), _stream(patches))
         return out
 
     def backward(self, genc, S, out=None, out_scale=1.0):

@@ -356,7 +356,7 @@ def main():
     target = torch.randn(1, model.visual.output_dim, generator=torch.Generator().manual_seed(2))
     target2 = torch.randn(1, model.visual.output_dim, generator=torch.Generator().manual_seed(3))
 
-    def make(transform_name, S_eff):
+    def make(transform_name, S_eff, **extra):
         """(engines [main, dual or None], synth) on freshly initialised parameters"""
         trf = transforms.transforms_fast if transform_name == 'fast' else transforms.normalize()
         torch.manual_seed(0)
@@ -375,6 +375,7 @@ def main():
             kw.update(param_kind='dwt', dwt=image_f.synth)
         else:
             leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
+        kw.update(extra)
         e1 = Engine(leaf, h, w, model, S_eff, [(target, -1.0)], **kw)
         e2 = Engine(leaf, h, w, model2, S_eff, [(target2, -1.0)], state=e1.state(), **kw) if dualmod is not None else None
         return e1, e2
@@ -501,6 +502,12 @@ def main():
             shutil.rmtree(tmpdir, ignore_errors=True)
 
     if legs is not None and a.config == 'c2':
+        # the opt-in split-precision forward (clip_fft.py --precise / aph_vit_forward_hilo): what closing the stress-weight parity gap costs
+        e_pr, e_prb = make(cfg['transform'], S, precise=True)
+        dtpr = timed(e_pr, e_prb, a.steps, a.warmup)
+        legs['precise'] = dict(value=a.steps / dtpr, unit='steps/s', ms_per_step=1e3 * dtpr / a.steps, skipped_steps=int(e_pr.guard[0]),
+                               note='--precise: patch-embedding and QKV GEMMs on hi + lo f16 activation pairs (twice their K); same workload as `value`')
+        del e_pr, e_prb
         # strong-scaling ceiling without an 8-GPU node: this GPU's step time at the per-rank shard sizes of 2 / 4 / 8 ranks (the collective
         # and its overlap are NOT in these numbers: 11 MB all-reduce per step)
         from aphantasia_amd.engine import shard_range

@@ -76,6 +76,7 @@ def get_args(argv=None):
     parser.add_argument(       '--clip-weights2', dest='clip_weights2', default=None, help='checkpoint of the --dualmod model (ViT-B-16.pt)')
     parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
     parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
+    parser.add_argument(       '--precise', action='store_true', help='split-precision ViT forward (hi + lo f16 operands on the patch-embedding and QKV GEMMs): closer to the fp32 CPU reference on weights with large dynamic range, ~8 %% slower')
     parser.add_argument(       '--aest-weights', dest='aest_weights', default=None, help="state dict of the LAION aesthetic head (sa_0_4_vit_b_32_linear.pth: "
                                "{'weight': [1,512], 'bias': [1]}); upstream downloads it (utils.py:402-413), there is no network here")
     parser.add_argument(       '--aest-weights2', dest='aest_weights2', default=None, help='the head of the --dualmod model (sa_0_4_vit_b_16_linear.pth)')
@@ -312,13 +313,13 @@ def main(argv=None):
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                  optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                 rank=rank, world=world, comm=comm, aest=aest1, **pk)
+                 rank=rank, world=world, comm=comm, aest=aest1, precise=a.precise, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                       optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                      rank=rank, world=world, comm=comm, aest=aest2, **pk)
+                      rank=rank, world=world, comm=comm, aest=aest2, precise=a.precise, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp

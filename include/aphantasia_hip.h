@@ -118,6 +118,8 @@ typedef struct aph_sample_geom {
 #define APH_OUT_NCHW_NORM 1  /* f32 [S,3,size,size], CLIP mean/std normalised (transforms.normalize) */
 #define APH_OUT_PATCH_F16 2  /* f16 [S*(size/patch)^2, 3*patch*patch] normalised = patch-embed GEMM operand; row = patch (s, gy, gx), column
                               * k = (iy*patch + ix)*3 + c: pixel-major inside the patch, channel fastest (aph_vit_set_weight permutes conv1.weight to match) */
+#define APH_OUT_PATCH_F16_HILO 4 /* aph_sample_fwd only: APH_OUT_PATCH_F16 rows written as [hi (3*patch^2) | lo (3*patch^2)], hi = f16(x), lo = f16(x - hi):
+                              * the operand of the split-precision forward aph_vit_forward_hilo */
 #define APH_GRAD_PATCH_F16 3 /* aph_sample_bwd only: gradient in the patch-major layout stored as f16 (aph_vit_backward_h) */
 
 #define APH_AUG_STRIDE 16
@@ -161,6 +163,8 @@ int aph_grid_warp(const float* d_img, const float* d_depth, int C, int H, int W,
                   float midpoint, float dlens, float* d_ws, float* d_out, void* stream);
 /* NCHW f32 [S,3,R,R] <-> patch-major (entry of model.encode_image for a caller-made batch) */
 int aph_patchify_f16(const float* d_nchw, int S, int R, int patch, void* d_patches_f16, void* stream);
+/* the same into the [hi | lo] rows of APH_OUT_PATCH_F16_HILO: d_patches_hilo f16 [S*(R/patch)^2, 2 * 3*patch^2] */
+int aph_patchify_f16_hilo(const float* d_nchw, int S, int R, int patch, void* d_patches_hilo, void* stream);
 int aph_unpatchify_f32(const float* d_patch_grad, int S, int R, int patch, float gscale, float* d_nchw_grad, void* stream);
 
 /* ---- CLIP ViT visual tower: model.encode_image (clip_fft.py:254) + its input-gradient ----- */
@@ -175,6 +179,12 @@ size_t aph_vit_workspace_bytes(const aph_vit* vit);
 int aph_vit_set_weight(aph_vit* vit, const char* name, const float* h_data, size_t count);
 /* d_patches f16 [S*P, 3*patch^2] (APH_OUT_PATCH_F16 layout) -> d_enc f32 [S, output_dim] */
 int aph_vit_forward(aph_vit* vit, const void* d_patches, int S, float* d_enc, void* stream);
+/* Opt-in SPLIT-PRECISION forward (clip_fft.py --precise): d_patches_hilo f16 [S*P, 2 * 3*patch^2] (APH_OUT_PATCH_F16_HILO rows [hi | lo]).
+ * The patch-embedding GEMM and every block's QKV GEMM take their activation operand as a hi + lo pair of f16 values (~22 bits; the GEMMs
+ * run over twice the K against the weights repeated along K): the two f16 roundings that dominate the input-gradient error on weights with
+ * realistic dynamic range (profiles/r04_precision_attribution.txt).  Same outputs / saved activations as aph_vit_forward; the backward
+ * (aph_vit_backward) is unchanged.  Costs the 13 GEMMs it doubles: ~8 % of a C2 step. */
+int aph_vit_forward_hilo(aph_vit* vit, const void* d_patches_hilo, int S, float* d_enc, void* stream);
 /* d_genc f32 [S, output_dim] (times the caller's loss scale) -> d_patch_grad f32 [S*P, 3*patch^2] times out_scale */
 int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream);
 /* same with the patch gradient stored as f16 (keep the loss scale in it: out_scale = 1, and undo it in aph_sample_bwd's

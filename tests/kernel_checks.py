@@ -183,6 +183,13 @@ def check_sampler_augment(lib, dev, H=40, W=48, S=6, size=16, patch=8):
     # the patch-major f16 emit (LDS-staged 16-byte stores for full tiles) holds the same values
     pm = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=aug, out_mode=_ffi.APH_OUT_PATCH_F16, lib=lib)
     assert torch.equal(pm.cpu(), to_patch_major(out.cpu(), patch).half())
+    # the split-precision rows [hi | lo] (APH_OUT_PATCH_F16_HILO): hi = the plain f16 emit, hi + lo = the f32 value to ~2^-22; with and without -tf fast
+    for a_ in (aug, None):
+        hl = ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=a_, out_mode=_ffi.APH_OUT_PATCH_F16_HILO, lib=lib).cpu()
+        f32 = to_patch_major(ops.sample_fwd(geom, img.detach()[0].to(dev).contiguous(), tb, aug=a_, lib=lib).cpu(), patch)
+        kp = 3 * patch * patch
+        assert hl.shape == (f32.shape[0], 2 * kp) and torch.equal(hl[:, :kp], f32.half())
+        assert (hl[:, :kp].float() + hl[:, kp:].float() - f32).abs().max().item() < 2e-6 * max(f32.abs().max().item(), 1.0)
     got = ops.sample_bwd(geom, gout.to(dev).contiguous(), tb, aug=aug, lib=lib)
     assert (got.cpu() - img.grad[0]).abs().max().item() < 3e-4 * img.grad.abs().max().item()
 
@@ -437,7 +444,7 @@ def check_gemm(lib, dev, shapes, tile_cfg=0, variants=(1, 0)):
 TINY = dict(input_resolution=32, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
 
 
-def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2, check_fuse=True):
+def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2, check_fuse=True, hilo=False):
     w = synthetic_visual_weights(cfg, 3)
     Rr, p = cfg['input_resolution'], cfg['patch_size']
     x = torch.randn(S, 3, Rr, Rr, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
@@ -445,8 +452,15 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2, check_fuse=Tr
     genc = torch.randn(S, cfg['output_dim'], generator=torch.Generator().manual_seed(2)) * 0.01
     (want * genc).sum().backward()
     vit = ops.VitHandle(cfg, w, max_batch=S + 1, lib=lib)
-    patches = ops.patchify(x.detach().to(dev).contiguous(), p, lib=lib)
-    enc = vit.forward(patches, S)
+    patches = ops.patchify(x.detach().to(dev).contiguous(), p, lib=lib, hilo=hilo)      # hilo: the split-precision forward (rows [hi | lo])
+    if hilo:
+        plain = ops.patchify(x.detach().to(dev).contiguous(), p, lib=lib)
+        kp = plain.shape[1]
+        assert torch.equal(patches[:, :kp], plain)
+        xs = plain.float() + patches[:, kp:].float()          # hi + lo reproduces the f32 pixels to ~2^-22
+        want_pm = to_patch_major(x.detach(), p).to(dev)
+        assert (xs - want_pm).abs().max().item() < 2e-6 * max(want_pm.abs().max().item(), 1.0)
+    enc = vit.forward(patches, S, hilo=hilo)
     ferr = (enc.cpu() - want.detach()).abs().max().item() / want.abs().max().item()
     assert ferr < fwd_tol, ferr
     LS = 1024.0
@@ -454,7 +468,7 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2, check_fuse=Tr
     gx = ops.unpatchify(gp, S, Rr, p, lib=lib)
     berr = (gx.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
     assert berr < bwd_tol, berr
-    if not check_fuse:
+    if not check_fuse or hilo:
         return ferr, berr
     # the fused LayerNorm pairs of the first block (and the unfilled fp32 gradient stream) against the separate kernels: the same
     # arithmetic on the same values, so the results are equal bit for bit

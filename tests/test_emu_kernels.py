@@ -130,6 +130,14 @@ def test_vit(emu):
     K.check_vit(emu, 'cpu')
 
 
+def test_vit_split_precision_forward(emu):
+    """aph_vit_forward_hilo / aph_patchify_f16_hilo: [hi | lo] patch rows and first-LayerNorm outputs, GEMMs over twice the K; the saved
+    activations serve the unchanged backward"""
+    fe, be = K.check_vit(emu, 'cpu', hilo=True)
+    cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)
+    K.check_vit(emu, 'cpu', cfg, S=5, hilo=True)
+
+
 def test_vit_50_tokens(emu):
     # T = 50 like ViT-B/32: four 16-row attention tiles with a ragged last one
     cfg = dict(input_resolution=112, patch_size=16, width=256, layers=1, heads=4, output_dim=128)

@@ -159,15 +159,32 @@ def test_c2_loss_curve_32cuts_200steps_vs_oracle_fixture():
 
 
 def test_stress_weights_loss_curve_60steps_vs_oracle_fixture():
-    """`stress_visual_weights` (LN gains 0.2-10, massive residual channels, peaky attention), 32 cuts, 60 free-running steps.  This
-    curve does NOT stay inside 1e-3 and cannot with fp16 operands: the oracle itself, re-run with Gaussian noise of 1e-4 max|g| added to
-    its spectrum gradient, leaves 1e-3 at step 12 and reaches 2.6e-3 (tools/exp/oracle_sensitivity.py, profiles/r03_oracle_sensitivity.txt),
-    while the HIP path's single-step gradient error on these weights is 2e-3 max|g| (test_vit_stress_weights below).  What is
-    asserted: the first steps match to 1e-3, the run never overflows, and the divergence stays at the level that noise model predicts."""
+    """`stress_visual_weights` (LN gains 0.2-10, massive residual channels, peaky attention), 32 cuts, 60 free-running steps, DEFAULT path
+    (f16 MFMA operands everywhere, as the reference itself runs CLIP on a GPU).  Round 4, with f16-representable weights on both sides (as
+    real checkpoints are): max |d loss| 1.0e-3, past 1e-3 for a few steps around step 12 -- the fp32 oracle with EVERY HIP f16 rounding
+    emulated lands at 8e-4 on this trajectory (tools/precision_attribution.py, profiles/r04_precision_attribution.txt), and any single one of
+    them moves it by 0.3-8e-4.  What holds 1e-3 here is the opt-in split-precision forward (next test); the default path is asserted at 2e-3."""
     worst, first, rms, got = _curve('c2_s32_stress')
     print('stress weights, 32 cuts, 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f' % (worst, first, rms))
-    assert first is None or first >= 4, first
-    assert worst < 5e-3 and rms < 0.1 and np.isfinite(got).all(), (worst, rms)
+    assert first is None or first >= 8, first
+    assert worst < 2e-3 and rms < 0.05 and np.isfinite(got).all(), (worst, rms)
+
+
+def test_stress_weights_loss_curve_60steps_precise_mode_vs_oracle_fixture():
+    """The same stress-weight curve with the opt-in SPLIT-PRECISION forward (Engine(precise=True) / clip_fft.py --precise /
+    aph_vit_forward_hilo: the cuts and every block's first LayerNorm output as hi + lo f16 pairs -- the two roundings
+    profiles/r04_precision_attribution.txt puts at the top): north_star's 1e-3 over all 60 steps."""
+    worst, first, rms, got = _curve('c2_s32_stress', precise=True)
+    print('stress weights, PRECISE mode, 32 cuts, 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f' % (worst, first, rms))
+    assert first is None and worst < 1e-3, (worst, first)
+    assert rms < 0.05 and np.isfinite(got).all(), rms
+
+
+def test_c2_loss_curve_200cuts_50steps_precise_mode_vs_oracle_fixture():
+    """plain synthetic weights, BASELINE's sample count, with the split-precision forward: at least as close as the default path"""
+    worst, first, rms, _ = _curve('c2_s200', precise=True)
+    print('C2 200 cuts, 50 free-running steps, PRECISE mode: max |d loss| %.2e, final block-mean RMS %.4f' % (worst, rms))
+    assert first is None and worst < 1e-3, (worst, first)
 
 
 def test_c2_fast_transform_step_vs_oracle(b32):
@@ -361,6 +378,13 @@ def test_vit_stress_weights(name):
     print('%s (%s): enc cos %.6f rel %.2e | input-grad cos %.6f rel %.2e | LOSS_SCALE %g finite' % (name, src, ecos, ferr, gcos, berr, LOSS_SCALE))
     assert ecos > 0.9999 and ferr < 1e-2, (ecos, ferr)
     assert gcos > 0.999 and berr < 5e-2, (gcos, berr)
+    # the split-precision forward on the same inputs: embedding and input gradient at least as close
+    enc2 = vit.forward(ops.patchify(x.detach().to(DEV).contiguous(), p, hilo=True), S, hilo=True)
+    ferr2 = (enc2.cpu() - want.detach()).abs().max().item() / want.abs().max().item()
+    gx2 = ops.unpatchify(vit.backward((genc * LOSS_SCALE).to(DEV).contiguous(), S, out_scale=1.0 / LOSS_SCALE), S, Rr, p).cpu()
+    berr2 = (gx2 - x.grad).abs().max().item() / x.grad.abs().max().item()
+    print('%s split-precision forward: enc rel %.2e (default %.2e) | input-grad rel %.2e (default %.2e)' % (name, ferr2, ferr, berr2, berr))
+    assert ferr2 < 1.2 * ferr + 1e-5 and berr2 < 1.2 * berr + 1e-5, (ferr2, ferr, berr2, berr)
 
 
 def test_loss_curve_stress_weights():
