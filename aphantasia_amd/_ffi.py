@@ -79,6 +79,7 @@ _PROTOTYPES = {
     'aph_gemm_f16_ld': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'aph_sim_loss': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_axpy_f32': (c_int, [c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
+    'aph_rgb_to_u8': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     'aph_linear_head': (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'aph_comm_unique_id': (c_int, [c_void_p]),
     'aph_comm_init': (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),

@@ -172,6 +172,21 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
+// The per-step frame (clip_fft.py:297-306 -> utils.checkout, utils.py:94-100): rgb f32 [3,H,W] in [0,1] -> uint8 [H,W,3],
+//     np.clip(img ** gamma * 255, 0, 255).astype(np.uint8)         (truncation; gamma = 1: no pow)
+// one pixel per thread and trip (the three planes are read coalesced; 2.7 MB out at 720p)
+__global__ void rgb_to_u8_kernel(const float* __restrict__ rgb, unsigned char* __restrict__ out, size_t n, float gamma) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = rgb[(size_t)c * n + p];
+      if (gamma != 1.0f) v = powf(v, gamma);
+      v = fminf(fmaxf(v * 255.0f, 0.0f), 255.0f);
+      out[p * 3 + c] = (unsigned char)v;
+    }
+  }
+}
+
 // (the gradient as 16-byte quads when its base is 16-byte aligned -- one quad per thread, every load of the launch in flight at
 // once; the scalar loop this replaces made ten dependent round trips per thread: 7.4 us for 11 MB)
 template <bool VEC>
@@ -324,6 +339,19 @@ int aph_axpy_f32(float* d_y, const float* d_x, float alpha, size_t n, void* stre
   grid = grid > 2048u ? 2048u : grid;
   APH_LAUNCH(axpy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, d_y, d_x, alpha, n);
   return aph_check_launch("aph_axpy_f32");
+  APH_CATCH
+}
+
+// The saved frame's conversion as ONE launch (it was four framework elementwise kernels on the step's stream):
+// d_rgb f32 [3,H,W] -> d_out uint8 [H,W,3] = clip(rgb ** gamma * 255, 0, 255) truncated, as utils.checkout does on the host (utils.py:94-100).
+int aph_rgb_to_u8(const float* d_rgb, int H, int W, float gamma, void* d_out, void* stream_) {
+  APH_TRY
+  if (!d_rgb || !d_out || H < 1 || W < 1 || !(gamma > 0.f)) return aph_fail(APH_ERR_ARG, "aph_rgb_to_u8: bad argument");
+  const size_t n = (size_t)H * W;
+  unsigned grid = (unsigned)((n + 255) / 256);
+  grid = grid > 4096u ? 4096u : grid;
+  APH_LAUNCH(rgb_to_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, d_rgb, (unsigned char*)d_out, n, gamma);
+  return aph_check_launch("aph_rgb_to_u8");
   APH_CATCH
 }
 

@@ -217,6 +217,9 @@ int aph_linear_head(const float* d_enc, int S, int D, const float* d_w, float bi
 /* d_y[i] += alpha * d_x[i] -- partial results summed inside a step (--enforce, clip_fft.py:271-275: two cut sets contribute to
  * one image gradient and one loss) */
 int aph_axpy_f32(float* d_y, const float* d_x, float alpha, size_t n, void* stream);
+/* the per-step frame (clip_fft.py:297-306 / utils.py:94-100 checkout): d_rgb f32 [3,H,W] in [0,1] -> d_out_u8 uint8 [H,W,3] =
+ * clip(rgb ** gamma * 255, 0, 255) truncated; one launch on `stream`, the caller copies it to the host asynchronously */
+int aph_rgb_to_u8(const float* d_rgb, int H, int W, float gamma, void* d_out_u8, void* stream);
 
 /* ---- optimiser: torch.optim.Adam / AdamW as configured at clip_fft.py:108-115 --------------- */
 /* d_hyper: 8 device floats {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale};

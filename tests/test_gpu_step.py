@@ -481,3 +481,27 @@ def test_illustrip_cli_frames_with_and_without_depth(tmp_path, monkeypatch, gen)
     illustrip.main(base[:-1] + [out2, '-d', '0.3', '--depth_dir', str(tmp_path / 'dm')])
     assert len([f for d, _, fs in os.walk(out2) for f in fs if f.endswith('.jpg')]) == 3
     assert len(os.listdir(str(tmp_path / 'dm'))) == 3              # one depth map per frame (depth.py:80-82)
+
+
+def test_frame_writer_matches_checkout_arithmetic(tmp_path):
+    """clip_fft.FrameWriter (aph_rgb_to_u8 on the step's stream + device->host copy on a side stream + JPEG threads) against the
+    reference's own conversion utils.checkout (utils.py:94-100): np.clip(img ** gamma * 255, 0, 255).astype(np.uint8), HWC."""
+    import clip_fft
+    from PIL import Image
+    h, w = 90, 130
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(3, h, w, generator=g) * 1.2 - 0.1).to(DEV).contiguous()            # some values outside [0, 1]
+    wr = clip_fft.FrameWriter(h, w)
+    for i, gamma in enumerate((1.0, 1.3)):
+        x = img.clamp_min(0.0) if gamma != 1.0 else img                                   # (pow of a negative number is NaN upstream too)
+        wr.put(x, os.path.join(tmp_path, '%d.png' % i), gamma)
+        want = np.clip((x.cpu().numpy().astype(np.float32) ** np.float32(gamma)) * 255, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+        torch.cuda.synchronize()
+        got = wr.dev[(wr.n - 1) % wr.RING].cpu().numpy()
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= (0 if gamma == 1.0 else 1), gamma      # powf vs numpy pow: last-ulp at a truncation boundary
+    wr.drain()
+    wr.close()
+    for i in range(2):
+        back = np.asarray(Image.open(os.path.join(tmp_path, '%d.png' % i)))                # PNG: lossless, what the pinned buffer held
+        assert back.shape == (h, w, 3)
+    assert np.array_equal(np.asarray(Image.open(os.path.join(tmp_path, '0.png'))), np.clip(img.cpu().numpy() * 255, 0, 255).astype(np.uint8).transpose(1, 2, 0))
