@@ -530,7 +530,9 @@ __device__ __forceinline__ int grad_col_of_off(int off, int p) {         // inve
 template <int OUT, int RBQ, int CPT>
 __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __restrict__ gout, float gscale, const int* __restrict__ table,
                                                                  float* __restrict__ grgb, Geom g, const AdjEntry* __restrict__ tab, int maxcs,
-                                                                 int RB, int NBC, int dbg) {
+                                                                 int RB, int NBC, int dbg, int XW) {
+  // [r4] XW: columns per workgroup; blockIdx.z selects the column segment [x0, x0 + XW) (frames wider than 768 threads x 3 columns: the
+  // 3840-wide C4 frame is two segments; a segment culls the cuts that do not reach it)
   constexpr int RBP = RBQ * 4, MAXV = 512;
   APH_DYN_SMEM(smem);
   float* U = reinterpret_cast<float*>(smem);                                   // [NBC][size][RBP]
@@ -541,6 +543,7 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
   int* vcount = vbox + 3 * MAXV;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.y, y0 = blockIdx.x * RB;
+  const int x0 = blockIdx.z * XW, x1 = (x0 + XW < g.W ? x0 + XW : g.W);
   const int rows = g.H - y0 < RB ? g.H - y0 : RB;
   const int cchan = is_patch<OUT>::v ? 1 : g.size * g.size;       // channel stride of the gradient layout (patch-major: channel fastest)
   const int ccut = is_patch<OUT>::v ? (g.size / g.patch) * (g.size / g.patch) * 3 * g.patch * g.patch : 3 * g.size * g.size;
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
         int cs = 0, ox = 0, oy = 0;
         if (v0 + tid < vend) {
           cs = table[3 * s]; ox = table[3 * s + 1]; oy = table[3 * s + 2];
-          hit = oy < y0 + rows && oy + cs > y0;
+          hit = oy < y0 + rows && oy + cs > y0 && ox < x1 && ox + cs > x0;
         }
         const unsigned long long m = __ballot(hit);
         if (hit) {
@@ -692,13 +695,13 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
           int coff[CPT][4];
 #pragma unroll
           for (int i = 0; i < CPT; ++i) {
-            const int x = i * nthr + tid;
+            const int x = x0 + i * nthr + tid;
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
               const int b = bh + bb;
               coff[i][bb] = -1;
               cw[i][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (b < nb && x < g.W) {
+              if (b < nb && x < x1) {
                 const int s = binfo[4 * b], csx = binfo[4 * b + 1], p = x - binfo[4 * b + 2];
                 if (csx > 0 && p >= 0 && p < csx && p < maxcs) {
                   const AdjEntry* ep = tab + ((size_t)s * 2 + 1) * maxcs + p;
@@ -726,8 +729,8 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
         }
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-          const int x = i * nthr + tid;
-          if (x >= g.W) continue;
+          const int x = x0 + i * nthr + tid;
+          if (x >= x1) continue;
           // up-sampling cuts (cs < size; none at 1280x720): the per-pixel generic path of crop_resize_adjoint_kernel.  Kept out of the
           // unrolled loop above (a loop the compiler does not unroll would index ce[] at run time and move it to scratch memory); the
           // sum of such a cut is added after the batch's table-driven cuts -- a fixed order all the same.
@@ -764,8 +767,8 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
   const size_t HW = (size_t)g.H * g.W;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int x = i * nthr + tid;
-    if (x >= g.W) continue;
+    const int x = x0 + i * nthr + tid;
+    if (x >= x1) continue;
 #pragma unroll
     for (int k = 0; k < RBQ; ++k)
 #pragma unroll
@@ -1146,19 +1149,23 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
   const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;
   APH_LAUNCH(tap_table_kernel<OUT>, dim3((maxcs + 127) / 128, 2, g.S), dim3(128), 0, st, table, tab, maxcs, g);
   // [r3] frames without wrap padding: the separable row-block kernel (APH_CROP_ADJOINT=gather keeps the round-2 gather kernel for A/B runs)
-  if (!crop_adjoint_gather() && g.Hp == g.H && g.Wp == g.W && g.py0 == 0 && g.px0 == 0 && g.W <= 2304 && g.size <= 256) {
-    const int cpt = g.W <= 1536 ? 2 : 3;                      // columns per thread, at most 768 threads (three waves per SIMD: 168 VGPRs)
-    int nthr = (((g.W + cpt - 1) / cpt) + 63) / 64 * 64;
+  if (!crop_adjoint_gather() && g.Hp == g.H && g.Wp == g.W && g.py0 == 0 && g.px0 == 0 && g.W <= 4 * 2304 && g.size <= 256) {
+    // column segments of at most 2304 (768 threads x 3 columns); [r4] wider frames (C4: 3840) take several segments per row block
+    const int nseg = (g.W + 2303) / 2304, xw = ((g.W + nseg - 1) / nseg + 3) & ~3;
+    const int cpt = xw <= 1536 ? 2 : 3;                       // columns per thread, at most 768 threads (three waves per SIMD: 168 VGPRs)
+    int nthr = (((xw + cpt - 1) / cpt) + 63) / 64 * 64;
     nthr = nthr < 256 ? 256 : nthr;
     // rows per workgroup: about one workgroup per CU over rows x 3 channels (85 row blocks), 12 or 16 accumulator rows per column
+    // (16 rows x 3 columns needs 168 VGPRs + scratch: segmented frames stay at 12)
     int rb = (g.H + 84) / 85;
     rb = rb < 4 ? 4 : (rb > 16 ? 16 : rb);
+    if (nseg > 1 && rb > 12) rb = 12;
     const int rbq = rb <= 12 ? 3 : 4, rbp = rbq * 4;
     int nbc = ADJ_NBC;
     auto lds = [&](int n) { return (size_t)n * g.size * rbp * 4 + 2 * (size_t)n * rbq * 8 * sizeof(QuadRow) + 2 * (size_t)n * 16 + 512 * 16 + 16; };
     while (nbc > 1 && lds(nbc) > 150 * 1024) --nbc;
     if (lds(nbc) <= 150 * 1024) {
-      const dim3 rgrid((g.H + rb - 1) / rb, 3);
+      const dim3 rgrid((g.H + rb - 1) / rb, 3, nseg);
 #ifdef APH_EXPERIMENTS      /* ablation hook (1 = no column pass, 2 = no row pass: WRONG gradients) -- only in a -DAPH_EXPERIMENTS build, never in the product library */
       static const int dbg = [] { const char* e = getenv("APH_SAMPLER_DBG"); return e ? atoi(e) : 0; }();
 #else
@@ -1168,7 +1175,7 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
 #define APH_ADJ_ROWS(RBQ, CPT)                                                                                                              \
   do {                                                                                                                                       \
     APH_ALLOW_SMEM((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), 150 * 1024);                                                                   \
-    APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg); \
+    APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg, xw); \
   } while (0)
       if (rbq == 3 && cpt == 2) APH_ADJ_ROWS(3, 2);
       else if (rbq == 3) APH_ADJ_ROWS(3, 3);

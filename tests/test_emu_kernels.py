@@ -63,6 +63,12 @@ def test_sampler_adjoint(emu, align, mode):
     K.check_sampler_adjoint(emu, 'cpu', align, mode)
 
 
+def test_sampler_adjoint_column_segments(emu):
+    """frames wider than 2304 columns: the separable crop adjoint runs one workgroup per (row block, channel, column SEGMENT); a segment culls
+    the cuts that do not reach it (C4's 3840-wide frame is two segments)"""
+    K.check_sampler_adjoint(emu, 'cpu', 'uniform', _ffi.APH_OUT_NCHW_RAW, H=30, W=2500, S=6, size=16, patch=8)
+
+
 def test_sampler_augment(emu):
     K.check_sampler_augment(emu, 'cpu')
     K.check_sampler_augment(emu, 'cpu', H=80, W=96, S=6, size=64, patch=16)      # full 32x32 tiles: LDS-staged patch-major emit

@@ -65,6 +65,9 @@ def test_sampler_adjoint(align, mode):
 def test_sampler_adjoint_full_size():
     K.check_sampler_adjoint(None, DEV, 'uniform', _ffi.APH_OUT_PATCH_F16, H=720, W=1280, S=12, size=224, patch=32)
     K.check_sampler_adjoint(None, DEV, 'overscan', _ffi.APH_OUT_NCHW_NORM, H=360, W=640, S=6, size=224, patch=32)
+    # wider than one column segment of the separable adjoint (2304): two / three segments, patch-major and planar gradients
+    K.check_sampler_adjoint(None, DEV, 'uniform', _ffi.APH_OUT_PATCH_F16, H=300, W=3840, S=8, size=224, patch=32)
+    K.check_sampler_adjoint(None, DEV, 'central', _ffi.APH_OUT_NCHW_RAW, H=260, W=5000, S=6, size=224, patch=32)
 
 
 def test_sampler_augment():

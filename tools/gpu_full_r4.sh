@@ -37,4 +37,4 @@ try:
 except Exception as e: print(sys.argv[1], 'failed', e)
 PY
 done
-tail -3 $O/${TAG}_pmc_traffic.txt $O/${TAG}_pmc_traffic_c4.txt
+tail -n 3 $O/${TAG}_pmc_traffic.txt; tail -n 3 $O/${TAG}_pmc_traffic_c4.txt
