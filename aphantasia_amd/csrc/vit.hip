@@ -355,8 +355,9 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
     vgemm(v, v->h, D, l.w_fc1, D, Mr, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
     vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, Mr, D, 4 * D, EpiResidual{x_next, l.x_mid, rs * D, l.b_fc2}, st);
   }
-  APH_LAUNCH(head_fwd_kernel, dim3(S, (v->E + 127) / 128), dim3(256), sizeof(float) * (D + 256), st, (const float*)v->x_last,
-             (const float*)v->ln_post_g, (const float*)v->ln_post_b, (const float*)v->proj, d_enc, T, D, v->E);
+  APH_ALLOW_SMEM(head_fwd_kernel, sizeof(float) * kHeadCuts * (D + 8 * 128));
+  APH_LAUNCH(head_fwd_kernel, dim3((S + kHeadCuts - 1) / kHeadCuts, (v->E + 127) / 128), dim3(1024), sizeof(float) * kHeadCuts * (D + 8 * 128), st,
+             (const float*)v->x_last, (const float*)v->ln_post_g, (const float*)v->ln_post_b, (const float*)v->proj, d_enc, S, T, D, v->E);
   return aph_check_launch("aph_vit_forward");
 }
 int aph_vit_forward(aph_vit* v, const void* d_patches, int S, float* d_enc, void* stream_) {

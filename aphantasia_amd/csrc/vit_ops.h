@@ -214,45 +214,74 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
 
 // ---------------------------------------------------------------------------------
 // head: enc[s] = LN_post(x[s*T + 0]) @ proj        (proj [D, E] f32).  fp32 throughout.
-// grid (S, E/128), 256 threads: 128 outputs x 2 halves of the D reduction, 8 independent partial sums per
-// thread so the proj loads pipeline instead of serialising on L2 latency.
+// [r4] grid (ceil(S / 4), E/128), 1024 threads: a workgroup takes FOUR cuts over its 128 outputs, so the 393 KB slice of proj it streams is
+// read once per four cuts (it was once per cut: 300 MB of L2 reads per launch at C2), and the D reduction is cut into EIGHT slices of
+// threads (it was two): a thread's chain of dependent 16-load batches is 6 long instead of 24 -- the kernel is bound by that chain
+// (23 us for 1.5 MB of weights), not by bytes.  The eight partial sums of an output are added in slice order (deterministic).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, const float* __restrict__ proj,
-                                                      float* __restrict__ enc, int T, int D, int E) {
+constexpr int kHeadCuts = 4;
+__global__ __launch_bounds__(1024) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ proj,
+                                                       float* __restrict__ enc, int S, int T, int D, int E) {
   APH_DYN_SMEM(smem);
-  float* y = reinterpret_cast<float*>(smem);     // [D]
-  float* part = y + D;                           // [256]
-  __shared__ float red[16];
-  const int s = blockIdx.x;
-  const float* row = x + (size_t)s * T * D;
-  float a = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) a += row[d];
-  const float mean = block_sum(a, red) / D;
-  float q = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) { const float c = row[d] - mean; q += c * c; }
-  const float rstd = rsqrtf(block_sum(q, red) / D + kLnEps);
-  for (int d = threadIdx.x; d < D; d += blockDim.x) y[d] = (row[d] - mean) * rstd * gamma[d] + beta[d];
+  float* y = reinterpret_cast<float*>(smem);     // [kHeadCuts][D]
+  float* part = y + kHeadCuts * D;               // [kHeadCuts][8][128]
+  const int s0 = blockIdx.x * kHeadCuts, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < kHeadCuts) {                         // LayerNorm of class row s0 + wave: one wave per row
+    const int s = s0 + wave;
+    if (s < S) {
+      const float* row = x + (size_t)s * T * D;
+      float a = 0.f;
+      for (int d = lane; d < D; d += 64) a += row[d];
+      const float mean = wave_sum(a) / D;
+      float q = 0.f;
+      for (int d = lane; d < D; d += 64) { const float c = row[d] - mean; q += c * c; }
+      const float rstd = rsqrtf(wave_sum(q) / D + kLnEps);
+      for (int d = lane; d < D; d += 64) y[wave * D + d] = (row[d] - mean) * rstd * gamma[d] + beta[d];
+    } else {
+      for (int d = lane; d < D; d += 64) y[wave * D + d] = 0.f;
+    }
+  }
   __syncthreads();
-  const int e = blockIdx.y * 128 + (threadIdx.x & 127), half = threadIdx.x >> 7;
-  const int dh = D >> 1, d0 = half * dh;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int el = threadIdx.x & 127, slice = threadIdx.x >> 7, e = blockIdx.y * 128 + el;
+  const int dn = D >> 3, d0 = slice * dn;
+  float acc[kHeadCuts];
+#pragma unroll
+  for (int c = 0; c < kHeadCuts; ++c) acc[c] = 0.f;
   if (e < E) {
     int d = d0;
-    for (; d + 16 <= d0 + dh; d += 16) {           // 16 independent loads in flight per thread: the loop is L2-latency bound
+    for (; d + 16 <= d0 + dn; d += 16) {           // 16 independent loads in flight per thread
       float w[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) w[u] = proj[(size_t)(d + u) * E + e];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u & 7] += y[d + u] * w[u];
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int c = 0; c < kHeadCuts; ++c) acc[c] += y[c * D + d + u] * w[u];
     }
-    for (; d < d0 + dh; ++d) acc[0] += y[d] * proj[(size_t)d * E + e];
+    for (; d < d0 + dn; ++d) {
+      const float w = proj[(size_t)d * E + e];
+#pragma unroll
+      for (int c = 0; c < kHeadCuts; ++c) acc[c] += y[c * D + d] * w;
+    }
   }
-  part[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+  for (int c = 0; c < kHeadCuts; ++c) part[(c * 8 + slice) * 128 + el] = acc[c];
   __syncthreads();
-  if (half == 0 && e < E) enc[(size_t)s * E + e] = part[threadIdx.x] + part[threadIdx.x + 128];
+  if (threadIdx.x < kHeadCuts * 128) {
+    const int c = threadIdx.x >> 7, s = s0 + c;
+    if (s < S && e < E) {
+      float t = part[(c * 8) * 128 + el];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += part[(c * 8 + k) * 128 + el];
+      enc[(size_t)s * E + blockIdx.y * 128 + el] = t;
+    }
+  }
 }
 
+// (Round 4, measured and rejected: this kernel with four cuts per workgroup -- thread = (quad of features, one of four slices of E), projT read
+// as 16-byte quads once per four cuts, slice partials through LDS, one wave per cut for the LayerNorm backward: 52 us against 27 at C2 and at
+// 24 cuts alike.  48 workgroups leave four fifths of the chip idle and the per-thread chain did not get shorter in time.)
 // head backward: genc [S,E] -> the class-token rows of dx (fp32) and dx16; every other row of dx must have been zeroed
 // by the caller (only the class token reaches the head; the other rows of dx16 are not read before they are rewritten).  projT = proj transposed [E, D].
 // One workgroup per image, one thread per feature d (blockDim.x == D <= 1024).
