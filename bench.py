@@ -301,6 +301,9 @@ def _spawned_rank(local_rank, world, port):
 def main():
     a = parse()
     cfg = a.cfg
+    if os.environ.get('APH_BENCH_WATCHDOG'):          # debugging aid: dump every thread's Python stack and exit if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['APH_BENCH_WATCHDOG']), exit=True)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU), exactly what torchrun would have done
         have = torch.cuda.device_count()
