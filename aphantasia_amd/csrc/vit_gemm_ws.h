@@ -153,8 +153,8 @@ __device__ __forceinline__ void ws_init(const E&, int, int, int, f32x4 (&v)[4], 
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void ws_init(const EpiResidual& e, int m4, int M, int n4, f32x4 (&v)[4], const float* lb) {
-  const f32x4 b = *reinterpret_cast<const f32x4*>(lb + n4);
+__device__ __forceinline__ void ws_init(const EpiResidual& e, int m4, int M, int n4, f32x4 (&v)[4], const float*) {
+  const f32x4 b = ld4(e.bias + n4);          // from global (3 KiB, L2-resident), not from the LDS copy: the first tile's init runs BEFORE the first barrier
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = m4 + r < M ? m4 + r : M - 1;                      // (rows past M: clamped read, never stored)
@@ -300,7 +300,6 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   const int frow = lane & 15, arow = wm * 64 + frow, brow = wn * 64 + frow, fchunk = lane >> 4;
   GemmFrags<F> f0, f1;
   int kt = 0, st = 0;
-  wait_vm_barrier<63>();                                                       // unit 0 has landed (and the bias vector is in LDS)
   auto init_tile = [&](int t) {
     int tm, tn;
     coords(t, tm, tn);
@@ -314,7 +313,8 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
 #pragma unroll
       for (int nt = 0; nt < F::TN; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f.a[mt], f.b[nt], acc[mt][nt]);
   };
-  init_tile(tile);
+  init_tile(tile);                                                             // [r4] the residual epilogue's 16 loads per lane go out before the wait below:
+  wait_vm_barrier<63>();                                                       // unit 0 has landed (and the bias vector is in LDS); vmcnt(63) does not wait for them
   gemm_load_frags<F>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
   for (int u = 0; u < U; ++u) {
     const half_t* As = lds + st * C::STAGE;

@@ -300,12 +300,12 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict_
   const float rstd = rsqrtf(block_sum(c * c, red) / D + kLnEps);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int e = 0;
-  for (; e + 16 <= E; e += 16) {                   // 16 independent loads in flight per thread (L2-latency bound loop)
-    float w[16];
+  for (; e + 32 <= E; e += 32) {                   // 32 independent loads in flight per thread (L2-latency bound loop: 16 batches at E = 512)
+    float w[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = projT[(size_t)(e + u) * D + d];
+    for (int u = 0; u < 32; ++u) w[u] = projT[(size_t)(e + u) * D + d];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u & 7] += ge[e + u] * w[u];
+    for (int u = 0; u < 32; ++u) acc[u & 7] += ge[e + u] * w[u];
   }
   for (; e < E; ++e) acc[0] += ge[e] * projT[(size_t)e * D + d];
   const float g = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) * gamma[d];
