@@ -509,6 +509,23 @@ def check_rgb_priors(lib, dev):
         assert err < 1e-4 * (2.0 * x.grad.abs().max().item() + 1e-4), err
 
 
+def check_rgb_to_u8(lib, dev):
+    """aph_rgb_to_u8 (the saved frame's conversion) vs utils.checkout's arithmetic (utils.py:94-100): np.clip(img ** g * 255, 0, 255).astype(uint8), HWC"""
+    from aphantasia_amd import _ffi
+    L = lib if lib is not None else _ffi.lib()
+    g = torch.Generator().manual_seed(8)
+    for (h, w, gamma) in ((7, 13, 1.0), (33, 50, 1.0), (20, 31, 1.3)):
+        x = torch.rand(3, h, w, generator=g) * 1.2 - 0.1
+        if gamma != 1.0:
+            x = x.clamp_min(0.0)
+        out = torch.zeros(h, w, 3, dtype=torch.uint8, device=dev)
+        xd = x.to(dev).contiguous()
+        L.call('aph_rgb_to_u8', ops.ptr(xd), h, w, float(gamma), ops.ptr(out), ops._stream(xd))
+        want = np.clip((x.numpy().astype(np.float32) ** np.float32(gamma)) * np.float32(255), 0, 255).astype(np.uint8).transpose(1, 2, 0)
+        d = np.abs(out.cpu().numpy().astype(int) - want.astype(int)).max()
+        assert d <= (0 if gamma == 1.0 else 1), (h, w, gamma, d)
+
+
 def check_rgb_sharp(lib, dev):
     """aph_rgb_sharp vs torch autograd on utils.py:265-268 derivat(img, 'naiv')"""
     from aphantasia_amd import _ffi

@@ -165,6 +165,10 @@ def test_rgb_sharp(emu):
     K.check_rgb_sharp(emu, 'cpu')
 
 
+def test_rgb_to_u8(emu):
+    K.check_rgb_to_u8(emu, 'cpu')
+
+
 def test_frame_affine(emu):
     K.check_frame_affine(emu, 'cpu')
 
