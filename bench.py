@@ -301,9 +301,12 @@ def _spawned_rank(local_rank, world, port):
 def main():
     a = parse()
     cfg = a.cfg
-    if os.environ.get('APH_BENCH_WATCHDOG'):          # debugging aid: dump every thread's Python stack and exit if the run is still going after N seconds
+    # watchdog: dump every thread's Python stack and exit if the run is still going after N seconds (APH_BENCH_WATCHDOG=N; multi-rank runs
+    # default to 900 s -- a rank stuck in a collective should fail loudly with a stack, not sit in the launcher's timeout)
+    wd = os.environ.get('APH_BENCH_WATCHDOG') or ('900' if (a.gpus > 1 or int(os.environ.get('WORLD_SIZE', 1)) > 1) else '')
+    if wd and int(wd) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['APH_BENCH_WATCHDOG']), exit=True)
+        faulthandler.dump_traceback_later(int(wd), exit=True)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU), exactly what torchrun would have done
         have = torch.cuda.device_count()
