@@ -770,12 +770,25 @@ inline int& gemm_ws_min_tiles() {
   return v;
 }
 
+// small M (everything below the wave-specialised kernel's threshold): the per-wave split-K kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 = on
+// (default), 0 = the shared-ring tile configurations below (kept for A/B measurements and the equivalence tests; aph_gemm_set_rs()).
+template <class Epi>
+inline void launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);   // vit_gemm_rs.h
+inline int& gemm_rs_mode() {
+  static int v = 1;
+  return v;
+}
+
 template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                         const SplitKSpace* sp = nullptr) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
   if (gemm_ws_min_tiles() > 0 && big_tiles >= gemm_ws_min_tiles() && N <= 4096 /* GemmWS::BIAS_MAX */ && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32()) {
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
+    return;
+  }
+  if (gemm_rs_mode() && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32()) {
+    launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);

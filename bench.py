@@ -61,6 +61,8 @@ def parse():
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-legs', action='store_true', help='skip the -tf none and with-save legs (N = 1 only has them)')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    p.add_argument('--vit-path', default=None, help='measurement switch: comma list of name=int pairs handed to the library\'s test hooks '
+                                                    '(rs: aph_gemm_set_rs, fused: aph_vit_set_fused_max_rows, ws: aph_gemm_set_ws_min_tiles)')
     a = p.parse_args()
     cfg = dict(CONFIGS[a.config])
     for k in ('size', 'samples', 'model', 'transform'):
@@ -338,6 +340,12 @@ def main():
     from aphantasia_amd import clip as aclip, transforms
     from aphantasia_amd.engine import Engine
     from aphantasia_amd.clip import LOSS_SCALE
+    if a.vit_path:                          # A/B runs only: the default line never passes this
+        from aphantasia_amd import _ffi
+        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', ws='aph_gemm_set_ws_min_tiles', wide='aph_gemm_set_rs_wide_min_tiles')
+        for kv in a.vit_path.split(','):
+            k, v = kv.split('=')
+            getattr(_ffi.lib().cdll, hooks[k])(int(v))
     # the step's collective: RCCL called directly through the C ABI (aph_allreduce_f32); torch.distributed only carried the
     # 128-byte unique id and does the barriers / the MAX over ranks of the timing contract.  APH_COMM=torch: all-reduce through
     # torch.distributed instead (cross-check)

@@ -215,6 +215,28 @@ def test_vit_forced_through_the_wave_specialised_gemm():
         L.cdll.aph_gemm_set_ws_min_tiles(prev)
 
 
+def test_gemm_per_wave_splitk_vs_matmul_and_reproducible():
+    """tile_cfg 14 / 15 / 16 (vit_gemm_rs.h): the small-M kernels -- every wave streams its own k-tiles through a private LDS ring with
+    counted vmcnt waits and NO barrier, which the interpreter cannot time: the ViT-B shapes at the shard sizes of 8 / 4 / 2 ranks, ragged and
+    single-k-tile cases against fp32 matmul, and the SAME BITS on every launch next to uneven load (a slot refilled too early or read
+    before its DMA landed shows up as a changing tile)"""
+    import torch
+    from aphantasia_amd import ops
+    for cfg in (14, 15, 16):
+        K.check_gemm(None, DEV, [(1200, 2304, 768), (1200, 768, 768), (1200, 3072, 768), (1200, 768, 3072), (1150, 768, 2304), (2400, 768, 3072),
+                                 (50, 768, 768), (50, 768, 3072), (24, 3072, 768), (70, 128, 64), (333, 256, 192), (4750, 2304, 768)], tile_cfg=cfg, variants=(0,))
+    g = torch.Generator().manual_seed(11)
+    for (M, N, Kd) in ((1200, 768, 3072), (1200, 2304, 768), (2150, 768, 2304), (50, 3072, 768)):
+        A = torch.randn(M, Kd, generator=g).half().to(DEV); Bt = torch.randn(N, Kd, generator=g).half().to(DEV)
+        for cfg in (14, 15, 16):
+            ref = ops.gemm_f16(A, Bt, tile_cfg=cfg).clone()
+            busy = torch.randn(4096, 4096, device=DEV)
+            for i in range(12):
+                if i % 3 == 0:
+                    busy = busy * 1.0001          # uneven load next to the launches
+                assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=cfg), ref), (M, N, Kd, cfg, i)
+
+
 def test_gemm_splitk_matches_and_is_deterministic():
     """split-K (tile_cfg 8 / 9): ordered last-block reduction -> same bits on every run, fp32-rounding close to the unsplit kernel"""
     import torch
