@@ -773,7 +773,7 @@ inline int& gemm_ws_min_tiles() {
 // small M (everything below the wave-specialised kernel's threshold): the per-wave split-K kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 = on
 // (default), 0 = the shared-ring tile configurations below (kept for A/B measurements and the equivalence tests; aph_gemm_set_rs()).
 template <class Epi>
-inline void launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);   // vit_gemm_rs.h
+inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);   // vit_gemm_rs.h
 inline int& gemm_rs_mode() {
   static int v = 1;
   return v;
@@ -787,10 +787,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32()) {
-    launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st);
-    return;
-  }
+  if (gemm_rs_mode() && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() && launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st)) return;
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
   static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)

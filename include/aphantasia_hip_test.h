@@ -28,8 +28,11 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
  *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
- *   14 / 15  64x64 per-wave split-K: each of the four waves streams its own k-tiles through a private LDS ring (5 / 4 slots), no barrier in
- *            the main loop, ordered 4-way sum at the end (vit_gemm_rs.h: the small-M default)        16  the same with 64x128 tiles
+ *   14 / 15  64x64 register-staged split-K: each of the four waves streams its own k-tiles (global_load_dwordx4 -> private LDS image ->
+ *            fragments; 4 / 3 k-steps of 32 in flight), no barrier in the main loop, ordered 4-way sum at the end (vit_gemm_rs.h: the small-M
+ *            default for narrow outputs)
+ *   16 / 17  64x256 A-resident: the 64 x K block of A stays in LDS, every wave streams the weight rows of its 64 columns (8 / 4 k-steps in
+ *            flight); needs N % 256 == 0 and K <= 1024 (the small-M default for wide outputs)
  *   22 / 24  128x128 split-K x2 / x4
  * | 0x100 (with 2, 4 or 5 only): measurement variant whose epilogue keeps the accumulators live but never stores (upper bound of
  *   what overlapping the store phase could gain: tools/exp/gemm_nostore.py).
@@ -53,11 +56,9 @@ int aph_vit_set_fuse_ln(int on);
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* Small-M GEMMs of the ViT (shapes below the wave-specialised kernel's threshold): 1 = per-wave split-K kernels (tile_cfg 14 / 16,
+/* Small-M GEMMs of the ViT (shapes below the wave-specialised kernel's threshold): 1 = register-staged kernels (tile_cfg 14 / 16,
  * default), 0 = the shared-ring tile configurations 1 / 2 / 10 (A/B measurements, equivalence tests).  Returns the previous value. */
 int aph_gemm_set_rs(int on);
-/* Number of 64x128 output tiles from which the per-wave split-K path uses 64x128 tiles instead of 64x64.  Returns the previous value. */
-int aph_gemm_set_rs_wide_min_tiles(int tiles);
 /* Tile order of the wave-specialised GEMM inside an XCD's run: groups of g row panels, column tile by column tile inside a group
  * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest; environment APH_GEMM_WS_PGROUP).  Returns the previous value. */
 int aph_gemm_set_ws_pgroup(int g);

@@ -111,10 +111,13 @@ def test_gemm(emu):
     # wave-specialised persistent kernel (vit_gemm_ws.h): producer / consumer waves, permuted Bt rows, register epilogue;
     # single unit, ragged single tile, 9 / 10 tiles on 3 workgroups with odd and even k-tile counts
     K.check_gemm(emu, 'cpu', [(70, 128, 64), (300, 256, 192), (700, 768, 192), (1100, 512, 128)], tile_cfg=5, variants=(0,))
-    # per-wave split-K kernels (vit_gemm_rs.h): private rings of 5 / 4 / 3 slots wrapping (K = 768: six k-steps per wave), waves without a
-    # k-tile (K = 64, 128), ragged M, uneven shares (K = 320, 448)
-    for cfg in (14, 15, 16):
-        K.check_gemm(emu, 'cpu', [(100, 128, 64), (130, 256, 192), (70, 128, 320), (200, 256, 768), (64, 128, 128), (33, 384, 448)], tile_cfg=cfg, variants=(0,))
+    # register-staged small-M kernels (vit_gemm_rs.h), step counts fixed at compile time per K.  Split-K (14 / 15: 4 / 3 k-steps in
+    # flight): two to eight k-steps per wave (the two images and the register sets wrap), ragged M
+    for cfg in (14, 15):
+        K.check_gemm(emu, 'cpu', [(100, 128, 256), (130, 256, 512), (70, 128, 768), (33, 384, 1024)], tile_cfg=cfg, variants=(0,))
+    # A-resident (16 / 17: 8 / 4 weight k-steps in flight): as many k-steps as the prefetch depth (K = 256) and more, ragged M, two column groups
+    for cfg in (16, 17):
+        K.check_gemm(emu, 'cpu', [(100, 256, 256), (130, 512, 512), (70, 256, 768), (33, 512, 1024)], tile_cfg=cfg, variants=(0,))
     # panel-grouped tile order (groups of 2 / 4 row panels, ragged last group: 3 and 5 panels)
     for g in (2, 4):
         prev = emu.cdll.aph_gemm_set_ws_pgroup(g)

@@ -215,20 +215,22 @@ def test_vit_forced_through_the_wave_specialised_gemm():
         L.cdll.aph_gemm_set_ws_min_tiles(prev)
 
 
-def test_gemm_per_wave_splitk_vs_matmul_and_reproducible():
-    """tile_cfg 14 / 15 / 16 (vit_gemm_rs.h): the small-M kernels -- every wave streams its own k-tiles through a private LDS ring with
-    counted vmcnt waits and NO barrier, which the interpreter cannot time: the ViT-B shapes at the shard sizes of 8 / 4 / 2 ranks, ragged and
-    single-k-tile cases against fp32 matmul, and the SAME BITS on every launch next to uneven load (a slot refilled too early or read
-    before its DMA landed shows up as a changing tile)"""
+def test_gemm_register_staged_small_m_vs_matmul_and_reproducible():
+    """tile_cfg 14 / 15 (split-K) and 16 / 17 (A-resident), vit_gemm_rs.h: the small-M kernels -- every wave stages its own operand stream
+    through registers and a private LDS image with no barrier in the main loop.  The ViT-B shapes at the shard sizes of 8 / 4 / 2 ranks,
+    ragged and single-k-tile cases against fp32 matmul, and the SAME BITS on every launch next to uneven load"""
     import torch
     from aphantasia_amd import ops
-    for cfg in (14, 15, 16):
-        K.check_gemm(None, DEV, [(1200, 2304, 768), (1200, 768, 768), (1200, 3072, 768), (1200, 768, 3072), (1150, 768, 2304), (2400, 768, 3072),
-                                 (50, 768, 768), (50, 768, 3072), (24, 3072, 768), (70, 128, 64), (333, 256, 192), (4750, 2304, 768)], tile_cfg=cfg, variants=(0,))
+    for cfg in (14, 15):
+        K.check_gemm(None, DEV, [(1200, 768, 768), (1200, 768, 3072), (1150, 768, 2304), (2400, 768, 3072), (50, 768, 768), (50, 768, 3072),
+                                 (70, 128, 256), (333, 256, 512), (4750, 768, 2304), (100, 128, 4096), (777, 768, 1536)], tile_cfg=cfg, variants=(0,))
+    for cfg in (16, 17):
+        K.check_gemm(None, DEV, [(1200, 2304, 768), (1200, 3072, 768), (24, 3072, 768), (50, 2304, 768), (70, 256, 256), (333, 512, 512),
+                                 (4750, 2304, 768), (2150, 3072, 768), (100, 1024, 1024)], tile_cfg=cfg, variants=(0,))
     g = torch.Generator().manual_seed(11)
-    for (M, N, Kd) in ((1200, 768, 3072), (1200, 2304, 768), (2150, 768, 2304), (50, 3072, 768)):
+    for (M, N, Kd, cfgs) in ((1200, 768, 3072, (14, 15)), (2150, 768, 2304, (14, 15)), (1200, 2304, 768, (16, 17)), (50, 3072, 768, (16, 17))):
         A = torch.randn(M, Kd, generator=g).half().to(DEV); Bt = torch.randn(N, Kd, generator=g).half().to(DEV)
-        for cfg in (14, 15, 16):
+        for cfg in cfgs:
             ref = ops.gemm_f16(A, Bt, tile_cfg=cfg).clone()
             busy = torch.randn(4096, 4096, device=DEV)
             for i in range(12):
