@@ -536,6 +536,20 @@ int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
   APH_CATCH
 }
 
+// Measurement hook: the register-staged small-M kernels with an f16 output and per-phase stamps of the chip-wide 100 MHz clock.
+// kind 0 = split-K 64x64 (stamps: entry, first fragments read, main loop done, past the barrier, end), 1 = A-resident 64x256 (entry, fill
+// issued, fill barrier passed, main loop done, end).  d_trace: (workgroups x 8) uint64 or NULL.
+int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, int kind, unsigned long long* d_trace, void* stream_) {
+  APH_TRY
+  if (!d_A || !d_Bt || !d_out || M < 1 || !gemm8_addressable(M, K, N, K) || (kind == 0 ? !gemm_sk_fits(N, K) : !gemm_ar_fits(N, K)))
+    return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: bad shape");
+  const EpiF16 epi{(half_t*)d_out, N, nullptr};
+  if (kind == 0) launch_gemm_sk<4>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
+  else launch_gemm_ar<4, 8>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
+  return aph_check_launch("aph_gemm_rs_probe");
+  APH_CATCH
+}
+
 // the attention kernels alone (unit tests, micro-benchmarks): mode 0 = forward (qkv -> att, lse), 1 = backward
 // ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16, att / datt [S*T, heads*64] f16, lse [S*heads*T] f32,
 // d_delta: S*heads*T floats of scratch, needed by the backward when T > 64.

@@ -58,6 +58,13 @@ __device__ __forceinline__ int rs_tile_index() {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// measurement hook (aph_gemm_rs_probe): chip-wide 100 MHz clock stamps of wave 0 of every workgroup, slot k of trace[wg][8]
+__device__ __forceinline__ void rs_stamp(unsigned long long* trace, int k) {
+#ifndef APH_EMU
+  if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 // ---- split-K kernel -----------------------------------------------------------------------------------------------------------------
 struct GemmSK {
   static constexpr int BM = 64, BN = 64, NTHREAD = 256;
@@ -70,9 +77,10 @@ struct GemmSK {
 // were not issued, and every wait drains the whole prefetch queue: found in the ISA of the first version).
 template <int NS, int PD, class Epi>
 __global__ __launch_bounds__(256) void gemm_sk_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb, int M, int N,
-                                                      Epi epi) {
+                                                      Epi epi, unsigned long long* __restrict__ trace) {
   using C = GemmSK;
   APH_DYN_SMEM(smem);
+  rs_stamp(trace, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   int m0, n0;
   {
@@ -128,6 +136,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const half_t* __restrict__
     if (PD < NS) load(PD, R[0]);
     wave_lds_fence();
     frags(f[0], ring);
+    rs_stamp(trace, 1);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) {
@@ -142,7 +151,9 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const half_t* __restrict__
     }
   }
   // the four partial tiles meet in LDS: [source wave][row tile][column tile][lane] as f32x4
+  rs_stamp(trace, 2);
   __syncthreads();                                                   // every wave is done with its images
+  rs_stamp(trace, 3);
   f32x4* part = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -162,27 +173,29 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const half_t* __restrict__
     epi.apply8(m, n0 + 16 * (lane >> 4), sum[0], sum[1]);
     epi.apply8(m, n0 + 16 * (lane >> 4) + 8, sum[2], sum[3]);
   }
+  rs_stamp(trace, 4);
 }
 
 template <int NS, int PD, class Epi>
-inline void launch_gemm_sk_n(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, Epi epi, hipStream_t st) {
+inline void launch_gemm_sk_n(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, Epi epi, hipStream_t st, unsigned long long* trace) {
   const dim3 grid((N / GemmSK::BN) * ((M + GemmSK::BM - 1) / GemmSK::BM));
   APH_ALLOW_SMEM((gemm_sk_kernel<NS, PD, Epi>), GemmSK::SMEM);
-  APH_LAUNCH((gemm_sk_kernel<NS, PD, Epi>), grid, dim3(GemmSK::NTHREAD), GemmSK::SMEM, st, A, lda, Bt, ldb, M, N, epi);
+  APH_LAUNCH((gemm_sk_kernel<NS, PD, Epi>), grid, dim3(GemmSK::NTHREAD), GemmSK::SMEM, st, A, lda, Bt, ldb, M, N, epi, trace);
 }
 // the K values the kernel is instantiated for (k-steps per wave = K / 128): every long-K linear of a ViT of width 256 ... 1024
 inline bool gemm_sk_fits(int N, int K) { return N % 64 == 0 && (K == 256 || K == 512 || K == 768 || K == 1024 || K == 1536 || K == 2304 || K == 3072 || K == 4096); }
 template <int PD, class Epi>
-inline void launch_gemm_sk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+inline void launch_gemm_sk(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
+                           unsigned long long* trace = nullptr) {
   switch (K) {
-    case 256: launch_gemm_sk_n<2, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 512: launch_gemm_sk_n<4, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 768: launch_gemm_sk_n<6, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 1024: launch_gemm_sk_n<8, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 1536: launch_gemm_sk_n<12, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 2304: launch_gemm_sk_n<18, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 3072: launch_gemm_sk_n<24, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    default: launch_gemm_sk_n<32, PD>(A, lda, Bt, ldb, M, N, epi, st); break;       // 4096
+    case 256: launch_gemm_sk_n<2, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 512: launch_gemm_sk_n<4, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 768: launch_gemm_sk_n<6, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 1024: launch_gemm_sk_n<8, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 1536: launch_gemm_sk_n<12, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 2304: launch_gemm_sk_n<18, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 3072: launch_gemm_sk_n<24, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    default: launch_gemm_sk_n<32, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;       // 4096
   }
 }
 
@@ -282,9 +295,10 @@ __device__ __forceinline__ void ar_tile(int ntm, int& tm, int& tn) {
 
 template <int NT, int NKS, int PD, class Epi>
 __global__ __launch_bounds__(256) void gemm_ar_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt, int ldb, int M, int N,
-                                                      Epi epi) {
+                                                      Epi epi, unsigned long long* __restrict__ trace) {
   using C = GemmAR<NT>;
   APH_DYN_SMEM(smem);
+  rs_stamp(trace, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   constexpr int nks = NKS;
   int tm, tn;
@@ -307,13 +321,16 @@ __global__ __launch_bounds__(256) void gemm_ar_kernel(const half_t* __restrict__
     rowoff[q] = ((unsigned)am * (unsigned)lda + L.lpc * 8) * 2u;
   }
   ar_fill_copy<NKS>(smem, Ab, rowoff, wave, L);
+  rs_stamp(trace, 1);
   __syncthreads();
+  rs_stamp(trace, 2);
   f32x4 acc[4][NT];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   W.template run<NKS>(acc, smem, smem + nks * 4096 + wave * (2 * C::WIMG), Bb, woff, L);
+  rs_stamp(trace, 3);
   // lane: token rows m0 + 16 mt + (lane & 15), columns n0 + 4 NT (lane >> 4) + 4 nt + r
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -323,24 +340,26 @@ __global__ __launch_bounds__(256) void gemm_ar_kernel(const half_t* __restrict__
       for (int j = 0; j < NT / 2; ++j) epi.apply8(m, n0 + 4 * NT * (lane >> 4) + 8 * j, acc[mt][2 * j], acc[mt][2 * j + 1]);
     }
   }
+  rs_stamp(trace, 4);
 }
 
 template <int NT, int NKS, int PD, class Epi>
-inline void launch_gemm_ar_n(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, Epi epi, hipStream_t st) {
+inline void launch_gemm_ar_n(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, Epi epi, hipStream_t st, unsigned long long* trace) {
   using C = GemmAR<NT>;
   const dim3 grid((N / C::BN) * ((M + C::BM - 1) / C::BM));
   APH_ALLOW_SMEM((gemm_ar_kernel<NT, NKS, PD, Epi>), C::smem(NKS * 32));
-  APH_LAUNCH((gemm_ar_kernel<NT, NKS, PD, Epi>), grid, dim3(C::NTHREAD), C::smem(NKS * 32), st, A, lda, Bt, ldb, M, N, epi);
+  APH_LAUNCH((gemm_ar_kernel<NT, NKS, PD, Epi>), grid, dim3(C::NTHREAD), C::smem(NKS * 32), st, A, lda, Bt, ldb, M, N, epi, trace);
 }
 // K = the width of a ViT (256 ... 1024): the block fits LDS
 inline bool gemm_ar_fits(int N, int K) { return N % GemmAR<4>::BN == 0 && (K == 256 || K == 512 || K == 768 || K == 1024); }
 template <int NT, int PD, class Epi>
-inline void launch_gemm_ar(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+inline void launch_gemm_ar(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
+                           unsigned long long* trace = nullptr) {
   switch (K) {
-    case 256: launch_gemm_ar_n<NT, 8, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 512: launch_gemm_ar_n<NT, 16, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    case 768: launch_gemm_ar_n<NT, 24, PD>(A, lda, Bt, ldb, M, N, epi, st); break;
-    default: launch_gemm_ar_n<NT, 32, PD>(A, lda, Bt, ldb, M, N, epi, st); break;       // 1024
+    case 256: launch_gemm_ar_n<NT, 8, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 512: launch_gemm_ar_n<NT, 16, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    case 768: launch_gemm_ar_n<NT, 24, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;
+    default: launch_gemm_ar_n<NT, 32, PD>(A, lda, Bt, ldb, M, N, epi, st, trace); break;       // 1024
   }
 }
 

@@ -73,6 +73,10 @@ int aph_mfma_rate(int blocks, int iters, const void* d_src, float* d_out, void* 
 int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, void* d_out2, const float* d_bias, int epi_kind,
                       unsigned long long* d_trace, void* stream);
 
+/* The register-staged small-M GEMMs (tile_cfg 14 / 16) with an f16 output and per-phase stamps of the chip-wide 100 MHz clock
+ * (tools/exp/gemm_rs_trace.py): kind 0 = split-K, 1 = A-resident; d_trace: (workgroups x 8) uint64 or NULL. */
+int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, int kind, unsigned long long* d_trace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
