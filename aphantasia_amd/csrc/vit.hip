@@ -7,6 +7,7 @@
 // d_enc, removed by `out_scale`) so fp16 gradient activations do not underflow.
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "aph_device.h"
 #include "aph_host.h"
@@ -15,6 +16,7 @@
 #include "vit_gemm_rs.h"
 #include "vit_ops.h"
 #include "vit_attn.h"
+#include "vit_block.h"
 
 using namespace aph;
 
@@ -121,19 +123,55 @@ int upload_f32(float* dst, const float* src, size_t rows, size_t cols, bool tran
   return hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 
-template <class Epi>
-void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  if (!v->prof_on) { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); return; }
+// a launch of the GEMM family, with its HIP event pair when the profile is on (bench.py roofline); flops = its algorithmic FLOPs
+template <class F>
+void vtimed(aph_vit* v, double flops, hipStream_t st, F&& launch) {
+  if (!v->prof_on) { launch(); return; }
   if (v->prof_used + 2 > v->prof_ev.size()) {
     hipEvent_t a, b;
     APH_HIP(hipEventCreate(&a)); APH_HIP(hipEventCreate(&b));
     v->prof_ev.push_back(a); v->prof_ev.push_back(b);
   }
   APH_HIP(hipEventRecord(v->prof_ev[v->prof_used], st));
-  launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk);
+  launch();
   APH_HIP(hipEventRecord(v->prof_ev[v->prof_used + 1], st));
   v->prof_used += 2;
-  v->prof_flops += 2.0 * M * N * K;
+  v->prof_flops += flops;
+}
+template <class Epi>
+void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
+  vtimed(v, 2.0 * M * N * K, st, [&] { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); });
+}
+
+// Fused block kernels (vit_block.h) for short sequences: used while the batch has at most this many token rows (0 = never).  Above it the
+// one-launch-per-operator path with the wave-specialised GEMM is the faster one (measured crossover: DESIGN.md section 4).
+#ifndef APH_VIT_FUSED_MAX_ROWS_DEFAULT
+#define APH_VIT_FUSED_MAX_ROWS_DEFAULT 4800
+#endif
+int g_fused_max_rows = APH_VIT_FUSED_MAX_ROWS_DEFAULT;
+inline bool vit_fused(const aph_vit* v, int S) { return v->T <= AT_T && v->D <= 1024 && (long long)S * v->T <= g_fused_max_rows; }
+
+void launch_qkv_attn(aph_vit* v, const Layer& l, int S, hipStream_t st) {
+  const int nv = v->D / 256;
+  auto go = [&](auto tag) {
+    constexpr int NV = decltype(tag)::value;
+    launch_blk_qkv_attn<NV, 8>(l.x_in, l.ln1_g, l.ln1_b, l.w_qkv, l.b_qkv, l.qkv, l.att, l.lse, S, v->T, v->heads, st);
+  };
+  switch (nv) {
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    default: go(std::integral_constant<int, 4>{}); break;
+  }
+}
+template <class Epi>
+void launch_ln_gemm(aph_vit* v, const float* x, int xs, int M, const float* g, const float* b, const half_t* Wt, int N, Epi epi, hipStream_t st) {
+  switch (v->D / 256) {
+    case 1: launch_blk_ln_gemm<1, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
+    case 2: launch_blk_ln_gemm<2, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
+    case 3: launch_blk_ln_gemm<3, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
+    default: launch_blk_ln_gemm<4, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
+  }
 }
 
 // g2 / b2 / out2: the next LayerNorm of the same rows fused behind this one (ln_fwd_kernel)
@@ -339,21 +377,30 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
   const int kx = hilo ? 2 : 1;
   vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
   const bool fuse = g_fuse_ln != 0;
+  const bool blk = !hilo && vit_fused(v, S);          // fused block kernels: LayerNorm inside the QKV / fc1 launches, attention behind the QKV GEMM
   launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st, 1,
-                             fuse ? v->layers[0].ln1_g : nullptr, fuse ? v->layers[0].ln1_b : nullptr, fuse ? v->h : nullptr, hilo ? 1 : 0);
+                             (fuse && !blk) ? v->layers[0].ln1_g : nullptr, (fuse && !blk) ? v->layers[0].ln1_b : nullptr, (fuse && !blk) ? v->h : nullptr, hilo ? 1 : 0);
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
-    if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
-    vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
-    launch_attn_fwd(attn_args(v, l, S), st);
+    if (blk) {
+      vtimed(v, 2.0 * M * 3 * D * D + 4.0 * S * v->heads * T * T * 64, st, [&] { launch_qkv_attn(v, l, S, st); });
+    } else {
+      if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
+      vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+      launch_attn_fwd(attn_args(v, l, S), st);
+    }
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
     // its attention runs on the S class rows alone: the same buffers addressed with a row pitch of T rows.
     const bool cls_only = li + 1 == v->L;
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
     vgemm(v, l.att, rs * D, l.w_o, D, Mr, D, D, EpiResidual{l.x_mid, l.x_in, rs * D, l.b_o}, st);
-    launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, Mr, T, nullptr, nullptr, nullptr, st, rs);
-    vgemm(v, v->h, D, l.w_fc1, D, Mr, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
+    if (blk) {
+      vtimed(v, 2.0 * Mr * 4 * D * D, st, [&] { launch_ln_gemm(v, l.x_mid, rs, Mr, l.ln2_g, l.ln2_b, l.w_fc1, 4 * D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st); });
+    } else {
+      launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, Mr, T, nullptr, nullptr, nullptr, st, rs);
+      vgemm(v, v->h, D, l.w_fc1, D, Mr, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
+    }
     vgemm(v, v->gact, 4 * D, l.w_fc2, 4 * D, Mr, D, 4 * D, EpiResidual{x_next, l.x_mid, rs * D, l.b_fc2}, st);
   }
   APH_ALLOW_SMEM(head_fwd_kernel, sizeof(float) * kHeadCuts * (D + 8 * 128));
@@ -449,6 +496,13 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
 int aph_vit_set_fuse_ln(int on) {
   const int prev = g_fuse_ln;
   g_fuse_ln = on ? 1 : 0;
+  return prev;
+}
+
+// largest batch (token rows S * T) that runs the fused block kernels of vit_block.h (0 = never).  Returns the previous value.
+int aph_vit_set_fused_max_rows(int rows) {
+  const int prev = g_fused_max_rows;
+  g_fused_max_rows = rows < 0 ? 0 : rows;
   return prev;
 }
 

@@ -114,24 +114,11 @@ __device__ __forceinline__ void at_mask_max(f32x4& st, int t16, int g4, int T, f
 // unrolled product loops cost more than the selects it saved: 151 against 144 us at C4's shape).
 __device__ __forceinline__ float at_p(float s_raw, float L2) { return fast_exp2(fminf(fmaf(s_raw, kSL, -L2), 0.f)); }
 
-// qkv [M,3D] f16 -> att [M,D] f16, lse [S*heads*T] f32 (log-sum-exp of the scaled scores)
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att,
-                                                           float* __restrict__ lse, int T, int heads) {
-  __shared__ __attribute__((aligned(16))) half_t lds[3 * 64 * 64];
-  half_t* Qs = lds;
-  half_t* Ks = lds + 64 * 64;
-  half_t* Vt = lds + 2 * 64 * 64;
-  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
-  const int D = heads * 64, ld = 3 * D;
-  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
-  {
-    const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
-    if (which == 0) at_stage_item(base, ld, T, item, Qs, nullptr);
-    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, nullptr);
-    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, nullptr, Vt);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, it = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+// One (cut, head) attention forward from LDS tiles: Qs, Ks row-major [64][64] (at_off), Vt the transposed slot-permuted image of V.
+// Wave `it` owns query tile it (16 rows); att_row0 = the head's 64 columns of the cut's first row in att [.., D]; lse_row0 likewise.
+__device__ __forceinline__ void at_fwd_tiles(const half_t* Qs, const half_t* Ks, const half_t* Vt, int T, int it, int lane, half_t* att_row0,
+                                             int D, float* lse_row0) {
+  const int c16 = lane & 15, g = lane >> 4;
   if (it * 16 >= T) return;
   f32x4 st[4];
 #pragma unroll
@@ -168,9 +155,29 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, g), p0, o);
     o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, 4 + g), p1, o);
-    if (i < T) store_h4(att + ((size_t)s * T + i) * D + h * 64 + dt * 16 + g * 4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    if (i < T) store_h4(att_row0 + (size_t)i * D + dt * 16 + g * 4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
   }
-  if (g == 0 && i < T) lse[((size_t)s * heads + h) * T + i] = mx * 0.125f + __logf(l);
+  if (g == 0 && i < T) lse_row0[i] = mx * 0.125f + __logf(l);
+}
+
+// qkv [M,3D] f16 -> att [M,D] f16, lse [S*heads*T] f32 (log-sum-exp of the scaled scores)
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ att,
+                                                           float* __restrict__ lse, int T, int heads) {
+  __shared__ __attribute__((aligned(16))) half_t lds[3 * 64 * 64];
+  half_t* Qs = lds;
+  half_t* Ks = lds + 64 * 64;
+  half_t* Vt = lds + 2 * 64 * 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  {
+    const int which = threadIdx.x >> 6, item = threadIdx.x & 63;
+    if (which == 0) at_stage_item(base, ld, T, item, Qs, nullptr);
+    else if (which == 1) at_stage_item(base + D, ld, T, item, Ks, nullptr);
+    else if (which == 2) at_stage_item(base + 2 * D, ld, T, item, nullptr, Vt);
+  }
+  __syncthreads();
+  at_fwd_tiles(Qs, Ks, Vt, T, threadIdx.x >> 6, threadIdx.x & 63, att + (size_t)s * T * D + h * 64, D, lse + ((size_t)s * heads + h) * T);
 }
 
 // backward: (qkv, lse, datt) -> dqkv [M,3D] f16   (`att` is not read: see D_i below)

@@ -1,0 +1,184 @@
+// Fused transformer-block kernels for short sequences (T <= 64 tokens per cut: CLIP ViT-B/32 has T = 50), gfx950 (round 5).
+//
+// At a shard of a few dozen cuts a ViT block is latency, not work: seven launches forward (LayerNorm, QKV, attention, out-proj, LayerNorm,
+// fc1, fc2) of 5-14 us each for 1-5 us of arithmetic, every one paying a kernel boundary plus a 2-3 us cold start of its first loads
+// (profiles/r05_gemm_rs_phase_trace.txt).  A cut's rows never meet another cut's inside a block, so the row-wise operators fold into the
+// GEMM that consumes or produces them WITHOUT any cross-workgroup hand-over, as long as a workgroup holds whole rows of the A operand:
+//   blk_qkv_attn_kernel   one workgroup per (cut, head): LayerNorm of the cut's rows straight into the resident A block (the arithmetic of
+//                         ln_fwd_kernel, same sums in the same order), the head's 192 QKV columns on the A-resident GEMM of vit_gemm_rs.h,
+//                         bias, the q / k / v tiles handed to the one-tile attention of vit_attn.h through LDS; writes qkv (saved for the
+//                         backward), att and lse in the unfused layouts;
+//   blk_ln_gemm_kernel    one workgroup per (64 rows, 256 columns): LayerNorm prologue + A-resident GEMM + any apply8 epilogue (fc1 +
+//                         QuickGELU).
+// Forward per block: 4 launches (this pair + the two narrow GEMMs with their residual epilogues) instead of 7; the saved activations keep
+// their layouts, so the backward may run fused or not independently.
+#pragma once
+#include "vit_gemm_rs.h"
+#include "vit_ops.h"
+#include "vit_attn.h"
+
+namespace aph {
+
+__device__ __forceinline__ half4 blk_h4(const f32x4& v) { return half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+
+// LayerNorm of 64 rows into the resident A block: rows r < nrows of x (row pitch xstride elements), the others as zeros.  Wave w takes the
+// rows w, w + 4, ...: all sixteen are requested before the first is reduced (rows past nrows re-read the last valid one: no load sits
+// behind a condition).  Element d of row r goes to k-step d >> 5, chunk (d >> 3) & 3 of the image (rs_swz placement).
+template <int NV>
+__device__ __forceinline__ void blk_ln_fill(char* a_img, const float* __restrict__ x, size_t xstride, int nrows, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int wave, int lane) {
+  constexpr int D = 256 * NV;
+  f32x4 v[16][NV];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = wave + 4 * j, rr = r < nrows ? r : nrows - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[j][i] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * xstride + i * 256 + lane * 4);
+  }
+  f32x4 g[NV], b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
+    b[i] = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = wave + 4 * j;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[j][i][0] + v[j][i][1] + v[j][i][2] + v[j][i][3];
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float c = v[j][i][e] - mean; q += c * c; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + kLnEps);
+    const bool live = r < nrows;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = live ? (v[j][i][e] - mean) * rstd * g[i][e] + b[i][e] : 0.f;
+      const int ks = i * 8 + (lane >> 3), c = (lane >> 1) & 3;
+      *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (lane & 1) * 8) = blk_h4(o);
+    }
+  }
+}
+
+// ---- LayerNorm + QKV (one head) + attention ------------------------------------------------------------------------------------------
+template <int NV>
+struct BlkQKV {
+  static constexpr int D = 256 * NV, NKS = 8 * NV, NT = 3;
+  static constexpr int SMEM = NKS * 4096 + 4 * 2 * NT * 1024;        // resident A block + per-wave weight images (the attention tiles alias the A block)
+};
+
+template <int NV, int PD>
+__global__ __launch_bounds__(256) void blk_qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const half_t* __restrict__ w_qkv, const float* __restrict__ b_qkv, half_t* __restrict__ qkv,
+                                                           half_t* __restrict__ att, float* __restrict__ lse, int S, int T, int heads) {
+  using C = BlkQKV<NV>;
+  constexpr int D = C::D;
+  APH_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int t = rs_tile_index(), h = t / S, s = t - h * S;          // heads slowest: the run of an XCD holds few heads' weight rows
+  const RSLane L(lane);
+  const char* Bb = reinterpret_cast<const char*>(w_qkv);
+  unsigned woff[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt)      // tile nt = section (q, k, v); tile row i = lrow is the head's column 16 wave + i of that section
+    woff[nt] = ((unsigned)(nt * D + h * 64 + 16 * wave + L.lrow) * (unsigned)D + L.lpc * 8) * 2u;
+  ARStream<3, PD> W;
+  W.template prefetch<C::NKS>(Bb, woff);                             // the first weight k-steps fly during the LayerNorm
+  blk_ln_fill<NV>(smem, x + (size_t)s * T * D, D, T, gamma, beta, wave, lane);
+  __syncthreads();
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  W.template run<C::NKS>(acc, smem, smem + C::NKS * 4096 + wave * (2 * 3 * 1024), Bb, woff, L);
+  __syncthreads();                                                   // every wave is done with the A block: its space becomes the attention tiles
+  half_t* Qs = reinterpret_cast<half_t*>(smem);
+  half_t* Ks = Qs + 4096;
+  half_t* Vt = Ks + 4096;
+  // lane: tokens 16 mt + (lane & 15), head columns c .. c + 3 of section nt
+  const int c = 16 * wave + 4 * (lane >> 4);
+  f32x4 bias[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(b_qkv + nt * D + h * 64 + c);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int tok = 16 * mt + (lane & 15);
+    const int sl = slot_of(tok);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const half4 hv = blk_h4(acc[mt][nt] + bias[nt]);
+      if (tok < T) *reinterpret_cast<half4*>(qkv + ((size_t)s * T + tok) * (3 * D) + nt * D + h * 64 + c) = hv;
+      if (nt == 0) *reinterpret_cast<half4*>(Qs + at_off(tok, c >> 3) + (c & 7)) = hv;
+      else if (nt == 1) *reinterpret_cast<half4*>(Ks + at_off(tok, c >> 3) + (c & 7)) = hv;
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vt[at_off(c + r, sl >> 3) + (sl & 7)] = hv[r];
+      }
+    }
+  }
+  __syncthreads();
+  at_fwd_tiles(Qs, Ks, Vt, T, wave, lane, att + (size_t)s * T * D + h * 64, D, lse + ((size_t)s * heads + h) * T);
+}
+
+template <int NV, int PD>
+inline void launch_blk_qkv_attn(const float* x, const float* gamma, const float* beta, const half_t* w_qkv, const float* b_qkv, half_t* qkv, half_t* att,
+                                float* lse, int S, int T, int heads, hipStream_t st) {
+  using C = BlkQKV<NV>;
+  APH_ALLOW_SMEM((blk_qkv_attn_kernel<NV, PD>), C::SMEM);
+  APH_LAUNCH((blk_qkv_attn_kernel<NV, PD>), dim3(S * heads), dim3(256), C::SMEM, st, x, gamma, beta, w_qkv, b_qkv, qkv, att, lse, S, T, heads);
+}
+
+// ---- LayerNorm + wide GEMM (K = width) + apply8 epilogue -------------------------------------------------------------------------------
+// rows: m0 + r of the compact row space 0 .. M - 1 (what the epilogue sees); x row m lives at x + m * xs * D (xs = T: class rows only)
+template <int NV, int PD, class Epi>
+__global__ __launch_bounds__(256) void blk_ln_gemm_kernel(const float* __restrict__ x, int xs, int M, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const half_t* __restrict__ Wt, int N, Epi epi) {
+  constexpr int D = 256 * NV, NKS = 8 * NV, NT = 4;
+  using C = GemmAR<NT>;
+  APH_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  int tm, tn;
+  ar_tile((M + C::BM - 1) / C::BM, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN + wave * 16 * NT;
+  const RSLane L(lane);
+  const char* Bb = reinterpret_cast<const char*>(Wt);
+  unsigned woff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) woff[nt] = ((unsigned)(n0 + 4 * NT * (L.lrow >> 2) + 4 * nt + (L.lrow & 3)) * (unsigned)D + L.lpc * 8) * 2u;
+  ARStream<NT, PD> W;
+  W.template prefetch<NKS>(Bb, woff);
+  const int nrows = M - m0 < C::BM ? M - m0 : C::BM;
+  blk_ln_fill<NV>(smem, x + (size_t)m0 * xs * D, (size_t)xs * D, nrows, gamma, beta, wave, lane);
+  __syncthreads();
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  W.template run<NKS>(acc, smem, smem + NKS * 4096 + wave * (2 * C::WIMG), Bb, woff, L);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + 16 * mt + (lane & 15);
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) epi.apply8(m, n0 + 4 * NT * (lane >> 4) + 8 * j, acc[mt][2 * j], acc[mt][2 * j + 1]);
+    }
+  }
+}
+
+template <int NV, int PD, class Epi>
+inline void launch_blk_ln_gemm(const float* x, int xs, int M, const float* gamma, const float* beta, const half_t* Wt, int N, Epi epi, hipStream_t st) {
+  using C = GemmAR<4>;
+  const int smem = C::smem(256 * NV);
+  APH_ALLOW_SMEM((blk_ln_gemm_kernel<NV, PD, Epi>), smem);
+  APH_LAUNCH((blk_ln_gemm_kernel<NV, PD, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(256), smem, st, x, xs, M, gamma, beta, Wt, N, epi);
+}
+
+}  // namespace aph

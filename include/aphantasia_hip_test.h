@@ -56,6 +56,9 @@ int aph_vit_set_fuse_ln(int on);
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
  * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
 int aph_gemm_set_ws_min_tiles(int tiles);
+/* Largest batch, in token rows (cuts x tokens per cut), whose forward runs the fused block kernels (LayerNorm inside the QKV / fc1
+ * launches, attention behind the QKV GEMM: csrc/vit_block.h; sequences of at most 64 tokens only); 0 = never.  Returns the previous value. */
+int aph_vit_set_fused_max_rows(int rows);
 /* Small-M GEMMs of the ViT (shapes below the wave-specialised kernel's threshold): 1 = register-staged kernels (tile_cfg 14 / 16,
  * default), 0 = the shared-ring tile configurations 1 / 2 / 10 (A/B measurements, equivalence tests).  Returns the previous value. */
 int aph_gemm_set_rs(int on);
