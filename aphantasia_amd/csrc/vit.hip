@@ -146,7 +146,7 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
 // Fused block kernels (vit_block.h) for short sequences: used while the batch has at most this many token rows (0 = never).  Above it the
 // one-launch-per-operator path with the wave-specialised GEMM is the faster one (measured crossover: DESIGN.md section 4).
 #ifndef APH_VIT_FUSED_MAX_ROWS_DEFAULT
-#define APH_VIT_FUSED_MAX_ROWS_DEFAULT 4800
+#define APH_VIT_FUSED_MAX_ROWS_DEFAULT 0
 #endif
 int g_fused_max_rows = APH_VIT_FUSED_MAX_ROWS_DEFAULT;
 inline bool vit_fused(const aph_vit* v, int S) { return v->T <= AT_T && v->D <= 1024 && (long long)S * v->T <= g_fused_max_rows; }
@@ -521,9 +521,9 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
 
 // small-M GEMMs (below the wave-specialised kernel's threshold) on the register-staged kernels of vit_gemm_rs.h (1, default) or on the shared-ring
 // tile configurations of vit_gemm.h (0).  Returns the previous value.
-int aph_gemm_set_rs(int on) {
+int aph_gemm_set_rs(int mode) {
   const int prev = gemm_rs_mode();
-  gemm_rs_mode() = on ? 1 : 0;
+  gemm_rs_mode() = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return prev;
 }
 // row panels per tile-order group of the wave-specialised GEMM (vit_gemm_ws.h `coords`): 0 = automatic, k > 0 = force.  Returns the previous value.
@@ -598,9 +598,27 @@ int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
   if (!d_A || !d_Bt || !d_out || M < 1 || !gemm8_addressable(M, K, N, K) || (kind == 0 ? !gemm_sk_fits(N, K) : !gemm_ar_fits(N, K)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: bad shape");
   const EpiF16 epi{(half_t*)d_out, N, nullptr};
+  if (kind == 2) {        // d_Bt = the fragment-major image written by aph_gemm_pack_frag (experiment: K = 768 only)
+    if (K != 768) return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: kind 2 is instantiated for K = 768");
+    using C = GemmAR<4>;
+    APH_ALLOW_SMEM((gemm_arp_kernel<4, 24, 8, EpiF16>), C::smem(768));
+    APH_LAUNCH((gemm_arp_kernel<4, 24, 8, EpiF16>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(256), C::smem(768), (hipStream_t)stream_,
+               (const half_t*)d_A, K, (const half_t*)d_Bt, M, N, epi, d_trace);
+    return aph_check_launch("aph_gemm_rs_probe");
+  }
   if (kind == 0) launch_gemm_sk<4>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
   else launch_gemm_ar<4, 8>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
   return aph_check_launch("aph_gemm_rs_probe");
+  APH_CATCH
+}
+
+// Bt [N, K] f16 -> fragment-major image for the A-resident kernel's 256-column groups (experiment hook)
+int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream_) {
+  APH_TRY
+  if (!d_Bt || !d_out || N % 256 || K % 32) return aph_fail(APH_ERR_ARG, "aph_gemm_pack_frag: bad shape");
+  const size_t total = (size_t)(N / 16) * (K / 32) * 64;
+  APH_LAUNCH((pack_frag_kernel<4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, (const half_t*)d_Bt, (half_t*)d_out, N, K);
+  return aph_check_launch("aph_gemm_pack_frag");
   APH_CATCH
 }
 

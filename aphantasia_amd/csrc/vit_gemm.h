@@ -770,10 +770,13 @@ inline int& gemm_ws_min_tiles() {
   return v;
 }
 
-// small M (everything below the wave-specialised kernel's threshold): the per-wave split-K kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 = on
-// (default), 0 = the shared-ring tile configurations below (kept for A/B measurements and the equivalence tests; aph_gemm_set_rs()).
+// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows (the class-row
+// GEMMs of the last block, a one-cut batch): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce launch,
+// 5.3 against 6.0 us at N = 768 ... 3072 over K = 768 and 12.5 against 16.7 us over K = 3072 at M = 50 (profiles/r05_gemm_rs_shapes.txt);
+// 2 = every shape below the wave-specialised kernel's threshold (measured SLOWER than the ring kernels from M ~ 1200 up: same file; kept for
+// A/B runs); 0 = never.  aph_gemm_set_rs().
 template <class Epi>
-inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st);   // vit_gemm_rs.h
+inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, bool wide);   // vit_gemm_rs.h
 inline int& gemm_rs_mode() {
   static int v = 1;
   return v;
@@ -787,7 +790,9 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() && launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st)) return;
+  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || M <= 128) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
+      launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
+    return;
   const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
   static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)

@@ -285,6 +285,100 @@ struct ARStream {
   }
 };
 
+__device__ __forceinline__ void ar_tile(int ntm, int& tm, int& tn);
+// The same stream from FRAGMENT-MAJOR packed weights: Bp [column group][wave][k-step][tile nt][lane][8 halfs], lane l = tile row l & 15,
+// chunk l >> 4 -- a wave's load of one fragment is 1 KiB contiguous and lands in the registers the MFMA reads: no LDS staging of the weights.
+template <int NT, int PD>
+struct ARStreamP {
+  half8 R[PD][NT];
+  __device__ __forceinline__ void request(int s, int d, const char* Bw) {          // Bw: this wave's stream + lane * 16
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) R[d][nt] = ldg8(Bw + (size_t)(s * NT + nt) * 1024);
+  }
+  template <int NKS>
+  __device__ __forceinline__ void prefetch(const char* Bw) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+      if (d < NKS) request(d, d, Bw);
+  }
+  template <int NKS>
+  __device__ __forceinline__ void run(f32x4 (&acc)[4][NT], const char* a_img, const char* Bw, const RSLane& L) {
+    half8 t[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) t[0][mt] = lds8(a_img + mt * 1024 + L.fpos);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      if (s + 1 < NKS) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t[(s + 1) & 1][mt] = lds8(a_img + (s + 1) * 4096 + mt * 1024 + L.fpos);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_16x16x32_f16(R[s % PD][nt], t[s & 1][mt], acc[mt][nt]);
+      if (s + PD < NKS) request(s + PD, s % PD, Bw);
+    }
+  }
+};
+
+// Bt [N, K] row-major -> the packed image for column groups of 64 NT (one thread per 16-byte piece)
+template <int NT>
+__global__ void pack_frag_kernel(const half_t* __restrict__ Bt, half_t* __restrict__ Bp, int N, int K) {
+  const int nks = K / 32;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)(N / 16) * nks * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  size_t r = idx >> 6;
+  const int nt = (int)(r % NT); r /= NT;
+  const int ks = (int)(r % nks); r /= nks;
+  const int wave = (int)(r & 3), tn = (int)(r >> 2);
+  const int i = lane & 15, row = tn * 64 * NT + wave * 16 * NT + 4 * NT * (i >> 2) + 4 * nt + (i & 3);
+  *reinterpret_cast<half8*>(Bp + idx * 8) = *reinterpret_cast<const half8*>(Bt + (size_t)row * K + ks * 32 + (lane >> 4) * 8);
+}
+
+template <int NT, int NKS, int PD, class Epi>
+__global__ __launch_bounds__(256) void gemm_arp_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bp, int M, int N, Epi epi,
+                                                       unsigned long long* __restrict__ trace) {
+  using C = GemmAR<NT>;
+  APH_DYN_SMEM(smem);
+  rs_stamp(trace, 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  int tm, tn;
+  ar_tile((M + C::BM - 1) / C::BM, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN + wave * 16 * NT;
+  const RSLane L(lane);
+  const char* Bw = reinterpret_cast<const char*>(Bp) + ((size_t)(tn * 4 + wave) * NKS * NT * 64 + lane) * 16;
+  ARStreamP<NT, PD> W;
+  W.template prefetch<NKS>(Bw);
+  unsigned rowoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int am = m0 + 16 * q + L.lrow;
+    am = am < M ? am : M - 1;
+    rowoff[q] = ((unsigned)am * (unsigned)lda + L.lpc * 8) * 2u;
+  }
+  ar_fill_copy<NKS>(smem, reinterpret_cast<const char*>(A), rowoff, wave, L);
+  rs_stamp(trace, 1);
+  __syncthreads();
+  rs_stamp(trace, 2);
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  W.template run<NKS>(acc, smem, Bw, L);
+  rs_stamp(trace, 3);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + 16 * mt + (lane & 15);
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) epi.apply8(m, n0 + 4 * NT * (lane >> 4) + 8 * j, acc[mt][2 * j], acc[mt][2 * j + 1]);
+    }
+  }
+  rs_stamp(trace, 4);
+}
+
 // tile order of the A-resident kernels: column groups slowest, so that the contiguous run of an XCD holds few column groups (their weight
 // rows stay in its L2) and all row blocks of each
 __device__ __forceinline__ void ar_tile(int ntm, int& tm, int& tn) {
@@ -366,8 +460,8 @@ inline void launch_gemm_ar(const half_t* A, int lda, const half_t* Bt, int ldb, 
 // which kernel: the A-resident one for wide outputs over K = width, split-K for the narrow outputs over a long K; false: neither is
 // instantiated for this shape (the caller falls back to the ring kernels of vit_gemm.h)
 template <class Epi>
-inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  if (N >= 4 * GemmAR<4>::BN && gemm_ar_fits(N, K)) launch_gemm_ar<4, 8>(A, lda, Bt, ldb, M, N, K, epi, st);
+inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, bool wide) {
+  if (wide && N >= 4 * GemmAR<4>::BN && gemm_ar_fits(N, K)) launch_gemm_ar<4, 8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (gemm_sk_fits(N, K)) launch_gemm_sk<4>(A, lda, Bt, ldb, M, N, K, epi, st);
   else return false;
   return true;

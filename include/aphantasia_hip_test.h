@@ -59,9 +59,10 @@ int aph_gemm_set_ws_min_tiles(int tiles);
 /* Largest batch, in token rows (cuts x tokens per cut), whose forward runs the fused block kernels (LayerNorm inside the QKV / fc1
  * launches, attention behind the QKV GEMM: csrc/vit_block.h; sequences of at most 64 tokens only); 0 = never.  Returns the previous value. */
 int aph_vit_set_fused_max_rows(int rows);
-/* Small-M GEMMs of the ViT (shapes below the wave-specialised kernel's threshold): 1 = register-staged kernels (tile_cfg 14 / 16,
- * default), 0 = the shared-ring tile configurations 1 / 2 / 10 (A/B measurements, equivalence tests).  Returns the previous value. */
-int aph_gemm_set_rs(int on);
+/* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
+ * GEMMs of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
+ * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
+int aph_gemm_set_rs(int mode);
 /* Tile order of the wave-specialised GEMM inside an XCD's run: groups of g row panels, column tile by column tile inside a group
  * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest; environment APH_GEMM_WS_PGROUP).  Returns the previous value. */
 int aph_gemm_set_ws_pgroup(int g);
@@ -78,6 +79,7 @@ int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
 
 /* The register-staged small-M GEMMs (tile_cfg 14 / 16) with an f16 output and per-phase stamps of the chip-wide 100 MHz clock
  * (tools/exp/gemm_rs_trace.py): kind 0 = split-K, 1 = A-resident; d_trace: (workgroups x 8) uint64 or NULL. */
+int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream);      /* experiment: fragment-major weights (probe kind 2) */
 int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, int kind, unsigned long long* d_trace, void* stream);
 
 #ifdef __cplusplus
