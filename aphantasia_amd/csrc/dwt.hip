@@ -494,10 +494,14 @@ void launch_idwt_coarse_adjoint(const IdwtLevels& lv, int C, size_t smem, hipStr
 // filter lengths the coarse-tail kernels are instantiated for (fully unrolled filter loops)
 inline bool idwt_coarse_length(int L) { return L == 2 || L == 4 || L == 6 || L == 8; }
 constexpr size_t kCoarseSmemMax = 150 * 1024;
-// APH_IDWT_COARSE=0: one launch per level throughout (A/B runs)
+// (-DAPH_EXPERIMENTS builds only: APH_IDWT_COARSE=0 in the environment = one launch per level throughout, for A/B runs)
 inline bool idwt_coarse_enabled() {
+#ifdef APH_EXPERIMENTS
   static const bool on = [] { const char* e = getenv("APH_IDWT_COARSE"); return !(e && e[0] == '0'); }();
   return on;
+#else
+  return true;
+#endif
 }
 
 void idwt_level_fwd(const float* d_ll, int ll_h, int ll_w, const float* d_highs, int h, int w, int C, const float* d_g0,

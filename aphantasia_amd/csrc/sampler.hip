@@ -1138,9 +1138,9 @@ void launch_crop_resize(const float* rgb, const int* table, void* out, const Geo
   APH_LAUNCH(crop_resize_strips_kernel<OUT>, dim3(8 * kStripSlots), dim3(256), 0, st, rgb, table, out, g, (const int*)lists, (const int*)counts, strip_cap(g));
 }
 
-// 1: always the round-2 gather kernel (environment APH_CROP_ADJOINT=gather, or aph_crop_adjoint_set_gather for A/B runs and tests)
+// 1: always the round-2 gather kernel (aph_crop_adjoint_set_gather: A/B runs and the equivalence tests)
 inline int& crop_adjoint_gather() {
-  static int v = [] { const char* e = getenv("APH_CROP_ADJOINT"); return (e && !strcmp(e, "gather")) ? 1 : 0; }();
+  static int v = 0;
   return v;
 }
 

@@ -199,9 +199,9 @@ void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const
     default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
   }
 }
-// LayerNorm pairs of the first block as one kernel each way, and no zero fill of the fp32 gradient stream (APH_VIT_FUSE_LN=0 or
-// aph_vit_set_fuse_ln(0): the separate kernels -- bit-identical, kept for A/B runs and the equivalence test)
-int g_fuse_ln = [] { const char* e = getenv("APH_VIT_FUSE_LN"); return (e && e[0] == '0') ? 0 : 1; }();
+// LayerNorm pairs of the first block as one kernel each way, and no zero fill of the fp32 gradient stream (aph_vit_set_fuse_ln(0): the
+// separate kernels -- bit-identical, kept for the equivalence test)
+int g_fuse_ln = 1;
 
 // attention launches: T <= 64 one-tile kernels, 64 < T <= 256 the blocked kernels (NB = ceil(T / 64))
 struct AttnArgs {
@@ -239,8 +239,7 @@ inline int attn_bwd_wgs(int items) {
 #ifdef APH_EMU
   return items < 3 ? items : 3;                     // exercises the item loop under the interpreter
 #else
-  static const int per_cu = [] { const char* e = getenv("APH_ATTN_BWD_WGS_PER_CU"); return e ? atoi(e) : 6; }();
-  if (per_cu <= 0) return items;                   // one item per workgroup (A/B runs)
+  constexpr int per_cu = 6;
   thread_local int dev_cached = -1, ncu = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return items;
@@ -668,14 +667,20 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   if (nostore) {          // measurement only: the same main loops with the output stores compiled out of the taken path
     const EpiNoStore en{d_C, N};
     if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, en, st);
+#ifdef APH_EXPERIMENTS
     else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, en, st);
+#endif
     else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, en, st, nullptr);
-    else return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: the no-store variant exists for tile_cfg 2, 4 and 5");
+    else return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: the no-store variant exists for tile_cfg 2 and 5 (4: -DAPH_EXPERIMENTS builds)");
     return aph_check_launch("aph_gemm_f16_ld");
   }
   if (tile_cfg == 1) launch_gemm_cfg<GemmSmall>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 2) launch_gemm_cfg<GemmBig>(A, lda, B, ldb, M, N, K, epi, st);
+#ifdef APH_EXPERIMENTS
   else if (tile_cfg == 4) launch_gemm8(A, lda, B, ldb, M, N, K, epi, st);
+#else
+  else if (tile_cfg == 4) return aph_fail(APH_ERR_UNSUPPORTED, "aph_gemm_f16_ld: tile_cfg 4 (phased 256x256 kernel) exists in -DAPH_EXPERIMENTS builds only");
+#endif
   else if (tile_cfg == 5) launch_gemm_ws_cfg<GemmWS>(A, lda, B, ldb, M, N, K, epi, st, nullptr);
   else if (tile_cfg == 8 || tile_cfg == 9 || tile_cfg == 22 || tile_cfg == 24) {                // split-K (2 / 4 ways) of the 64x64 configuration, private workspace
     static SplitKSpace sp;

@@ -300,6 +300,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
   epi.apply8(m, n, a, b);
 }
 
+#ifdef APH_EXPERIMENTS       // a measured-and-superseded kernel family: no BASELINE configuration launches it (the wave-specialised kernel takes every
+                             // shape it was tuned for); kept compilable for A/B runs only
 // ---- phased 256x256x64 kernel (cdna_hip_programming.md section 5.5, "8-phase" schedule) ----------------------
 // 8 waves as 2 (M) x 4 (N), 128x64 of C per wave, double-buffered 64 KiB stages.  A k-tile is worked off in FOUR
 // phases, one C quadrant of the wave (64x32, 16 MFMAs over K = 64) each, in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0)
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(512) void gemm8_f16_kernel(const half_t* __restrict
   }
 }
 
+#endif  // APH_EXPERIMENTS
+
 // ---- epilogues: apply8 gets 8 consecutive columns n..n+7 of row m -------------------------------------------
 __device__ __forceinline__ void store_h4(half_t* p, float a, float b, float c, float d) {
   half4 h = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
@@ -652,13 +656,10 @@ struct EpiPatchEmbed {   // token row s*T + 1 + p  <-  patch row s*P + p ;  + po
 #ifndef APH_GEMM_WS_MIN_TILES_DEFAULT
 #define APH_GEMM_WS_MIN_TILES_DEFAULT 160
 #endif
-// MFMA shape of the main loops: 1 = v_mfma_f32_32x32x16_f16, 0 = v_mfma_f32_16x16x32_f16.  Default below; the environment
-// variable APH_GEMM_MFMA32 (read once) or aph_gemm_set_mfma32() override it for A/B measurements.
-#ifndef APH_GEMM_MFMA32_DEFAULT
-#define APH_GEMM_MFMA32_DEFAULT 0
-#endif
+// MFMA shape of the ring kernels' main loops: 0 = v_mfma_f32_16x16x32_f16 (what the product runs: measured faster on MI355X with real
+// operands), 1 = v_mfma_f32_32x32x16_f16 (aph_gemm_set_mfma32(): kept for the layout tests and A/B measurements).
 inline int& gemm_mfma32() {
-  static int v = [] { const char* e = getenv("APH_GEMM_MFMA32"); return e ? (atoi(e) != 0 ? 1 : 0) : APH_GEMM_MFMA32_DEFAULT; }();
+  static int v = 0;
   return v;
 }
 
@@ -718,13 +719,11 @@ inline void launch_gemm_splitk(const half_t* A, int lda, const half_t* Bt, int l
   APH_LAUNCH((splitk_reduce_kernel<Epi>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (const float*)sp.ws, splits, M, N, epi);
 }
 
-// workgroups of a persistent launch: one per CU of the current device (APH_GEMM8_PERSIST=0: one tile per workgroup, for A/B runs)
-inline int gemm8_persistent_wgs() {
+// workgroups of a persistent launch: one per CU of the current device
+inline int gemm_persistent_wgs() {
 #ifdef APH_EMU
   return 3;                                        // exercises the tile loop (and its remainders) under the interpreter
 #else
-  static const int persist = [] { const char* e = getenv("APH_GEMM8_PERSIST"); return e ? atoi(e) : 1; }();
-  if (!persist) return 1 << 30;
   thread_local int dev_cached = -1, ncu = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 1 << 30;
@@ -741,6 +740,7 @@ inline bool gemm8_addressable(int M, int lda, int N, int ldb) {
   return (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldb * 2 < ((size_t)1 << 32);
 }
 
+#ifdef APH_EXPERIMENTS
 template <class Epi>
 inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
   const int ntiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
@@ -748,12 +748,14 @@ inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, in
     APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, true>), Gemm8::SMEM);
     APH_LAUNCH((gemm8_f16_kernel<Epi, true>), dim3(ntiles), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K, epi, ntiles);
   } else {
-    const int wgs = gemm8_persistent_wgs();
+    const int wgs = gemm_persistent_wgs();
     APH_ALLOW_SMEM((gemm8_f16_kernel<Epi, false>), Gemm8::SMEM);
     APH_LAUNCH((gemm8_f16_kernel<Epi, false>), dim3(ntiles < wgs ? ntiles : wgs), dim3(Gemm8::NTHREAD), Gemm8::SMEM, st, A, lda, Bt, ldb, M, N, K,
                epi, ntiles);
   }
 }
+
+#endif  // APH_EXPERIMENTS
 
 // tile choice, from the measured sweep over the ViT-B shapes at 1/2/4/8-rank shard sizes (tools/exp/tune_table.py):
 //   256x256 phased   wide outputs with >= 400 such tiles (N = 3072 at full batch: 456; QKV's 342 tiles take the 256x128 path --
@@ -764,9 +766,9 @@ inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, in
 template <class Epi>
 inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                            unsigned long long* trace = nullptr);   // vit_gemm_ws.h
-// the wave-specialised persistent kernel takes every shape with at least this many 256x128 tiles (APH_GEMM_WS_MIN_TILES; 0 = never)
+// the wave-specialised persistent kernel takes every shape with at least this many 256x128 tiles (aph_gemm_set_ws_min_tiles(); 0 = never)
 inline int& gemm_ws_min_tiles() {
-  static int v = [] { const char* e = getenv("APH_GEMM_WS_MIN_TILES"); return e ? atoi(e) : APH_GEMM_WS_MIN_TILES_DEFAULT; }();
+  static int v = APH_GEMM_WS_MIN_TILES_DEFAULT;
   return v;
 }
 
@@ -793,11 +795,8 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   if (gemm_rs_mode() && (gemm_rs_mode() > 1 || M <= 128) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
       launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
     return;
-  const int huge_tiles = (N / Gemm8::BN) * ((M + Gemm8::BM - 1) / Gemm8::BM);
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
-  static const int gemm8_min = [] { const char* e = getenv("APH_GEMM8_MIN_TILES"); return e ? atoi(e) : 400; }();     // (experiment hook)
-  if (N % Gemm8::BN == 0 && huge_tiles >= gemm8_min && gemm8_addressable(M, lda, N, ldb)) launch_gemm8(A, lda, Bt, ldb, M, N, K, epi, st);
-  else if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
+  if (big_tiles >= 160) launch_gemm_cfg<GemmBig>(A, lda, Bt, ldb, M, N, K, epi, st);
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {
     const int splits = choose_splits(M, N, K, sp);

@@ -346,9 +346,9 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
 }
 
 // row panels per tile-order group (see `coords` in the kernel): 4 when more than one round of tiles shares the weights (wide outputs), 1 = the
-// plain n-fastest order otherwise.  APH_GEMM_WS_PGROUP / aph_gemm_set_ws_pgroup(): 0 = automatic, k > 0 = force k (A/B measurements)
+// plain n-fastest order otherwise.  aph_gemm_set_ws_pgroup(): 0 = automatic, k > 0 = force k (A/B measurements, the tile-order tests)
 inline int& gemm_ws_pgroup_override() {
-  static int v = [] { const char* e = getenv("APH_GEMM_WS_PGROUP"); return e ? atoi(e) : 0; }();
+  static int v = 0;
   return v;
 }
 inline int gemm_ws_panel_group(int ntn, int ntm) {
@@ -361,16 +361,9 @@ template <class C, class Epi>
 inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                                unsigned long long* trace) {
   const int ntiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
-  const int cus = gemm8_persistent_wgs();
+  const int cus = gemm_persistent_wgs();
   const int wgs = cus > (1 << 20) ? cus : cus * C::WG_PER_CU;
   APH_ALLOW_SMEM((gemm_ws_kernel<C, Epi>), C::SMEM_TOTAL);
-#ifndef APH_EMU
-  if (getenv("APH_WS_OCC")) {       // (experiment aid) what the runtime says about residency
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_ws_kernel<C, Epi>, C::NTHREAD, C::SMEM_TOTAL);
-    fprintf(stderr, "gemm_ws_kernel<BM %d>: occupancy API says %d workgroup(s) per CU (threads %d, LDS %d)\n", C::BM, nb, C::NTHREAD, C::SMEM_TOTAL);
-  }
-#endif
   APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles,
              gemm_ws_panel_group(N / C::BN, (M + C::BM - 1) / C::BM), trace);
 }

@@ -23,7 +23,7 @@ int aph_attn_test(const void* d_qkv, void* d_att, float* d_lse, const void* d_da
 int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* d_C, void* stream);
 /* same with explicit row pitches (elements, multiples of 8) and an explicit tile configuration:
  *    0  automatic (the shape heuristic of launch_gemm)
- *    1  64x64, 4 waves            2  256x128, 8 waves, 3-stage ring       4  256x256 phased (needs N % 256 == 0)
+ *    1  64x64, 4 waves            2  256x128, 8 waves, 3-stage ring       4  256x256 phased (N % 256 == 0; -DAPH_EXPERIMENTS builds only)
  *    5  256x128 wave-specialised persistent (2 DMA producer waves + 8 MFMA consumer waves, register epilogue: vit_gemm_ws.h)
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
@@ -41,7 +41,8 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
                     void* stream);
 
 /* Crop / resize adjoint of aph_sample_bwd: 1 = always the per-pixel gather kernel (round 2), 0 = automatic (the separable row-block kernel
- * on frames without wrap padding).  Process-wide, returns the previous value; environment APH_CROP_ADJOINT=gather sets the initial value. */
+ * on frames without wrap padding).  Process-wide, returns the previous value.  (No environment variable changes which kernels the library
+ * runs: every switch here is an explicit call.) */
 int aph_crop_adjoint_set_gather(int on);
 
 /* MFMA shape of the GEMM main loops launched from now on (process-wide): 0 = v_mfma_f32_16x16x32_f16 (default: measured
@@ -49,12 +50,11 @@ int aph_crop_adjoint_set_gather(int on);
  * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
 int aph_gemm_set_mfma32(int on);
 /* the first block's LayerNorm pairs (ln_pre + ln_1 forward, ln_1 + ln_pre backward) as one kernel each and no zero fill of the
- * fp32 gradient stream: on (1, default; APH_VIT_FUSE_LN=0 in the environment turns it off) / off (0).  Bit-identical either way.
+ * fp32 gradient stream: on (1, default) / off (0).  Bit-identical either way.
  * Returns the previous value.  Captured graphs keep the setting they were recorded with. */
 int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
- * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes;
- * environment variable APH_GEMM_WS_MIN_TILES sets the initial value). */
+ * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
 /* Largest batch, in token rows (cuts x tokens per cut), whose forward runs the fused block kernels (LayerNorm inside the QKV / fc1
  * launches, attention behind the QKV GEMM: csrc/vit_block.h; sequences of at most 64 tokens only); 0 = never.  Returns the previous value. */
@@ -64,7 +64,7 @@ int aph_vit_set_fused_max_rows(int rows);
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
 int aph_gemm_set_rs(int mode);
 /* Tile order of the wave-specialised GEMM inside an XCD's run: groups of g row panels, column tile by column tile inside a group
- * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest; environment APH_GEMM_WS_PGROUP).  Returns the previous value. */
+ * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest).  Returns the previous value. */
 int aph_gemm_set_ws_pgroup(int g);
 /* Pure-MFMA rate probe (bench.py `roofline.peak_measured`): `blocks` workgroups of 8 waves run `iters` x 32 v_mfma_f32_16x16x32_f16 on
  * operands read once from d_src (>= 128 KiB of f16; random data sustains less than zeros: the part is power limited), nothing stored unless a

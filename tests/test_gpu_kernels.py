@@ -165,10 +165,9 @@ def test_gemm_mfma_layout():
 
 
 def test_gemm_every_tile_config():
-    for cfg in (1, 2, 4, 10):
+    for cfg in (1, 2, 10):
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
     K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64)], tile_cfg=11, variants=(0,))       # two workgroups per CU (2-stage ring)
-    K.check_gemm(None, DEV, [(9500, 3072, 768), (18715, 3072, 768)], tile_cfg=4, variants=(0,))   # persistent loop: 456 / 888 tiles on 256 CUs
 
 
 def test_gemm_wave_specialised_vs_matmul_and_reproducible():
@@ -223,7 +222,7 @@ def test_gemm_register_staged_small_m_vs_matmul_and_reproducible():
     from aphantasia_amd import ops
     for cfg in (14, 15):
         K.check_gemm(None, DEV, [(1200, 768, 768), (1200, 768, 3072), (1150, 768, 2304), (2400, 768, 3072), (50, 768, 768), (50, 768, 3072),
-                                 (70, 128, 256), (333, 256, 512), (4750, 768, 2304), (100, 128, 4096), (777, 768, 1536)], tile_cfg=cfg, variants=(0,))
+                                 (70, 128, 256), (333, 256, 1024), (4750, 768, 2304)], tile_cfg=cfg, variants=(0,))
     for cfg in (16, 17):
         K.check_gemm(None, DEV, [(1200, 2304, 768), (1200, 3072, 768), (24, 3072, 768), (50, 2304, 768), (70, 256, 256), (333, 512, 512),
                                  (4750, 2304, 768), (2150, 3072, 768), (100, 1024, 1024)], tile_cfg=cfg, variants=(0,))
