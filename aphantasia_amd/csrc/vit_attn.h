@@ -113,6 +113,17 @@ __device__ __forceinline__ void at_mask_max(f32x4& st, int t16, int g4, int T, f
 // One v_min instead of a compare + select per score, and no branch between the MFMAs (a wave-uniform "last tile only" branch inside the
 // unrolled product loops cost more than the selects it saved: 151 against 144 us at C4's shape).
 __device__ __forceinline__ float at_p(float s_raw, float L2) { return fast_exp2(fminf(fmaf(s_raw, kSL, -L2), 0.f)); }
+// dS of a key / query >= T is -p D_i / 8 with p up to 1 (no mask above): finite in fp32, but with a large loss scale it can leave the f16
+// range, and inf x 0 against the zero operand rows would be NaN where the masked form gave an exact 0.  One v_med3 keeps every dS inside
+// the f16 range before the conversion (a valid dS that large has overflowed anyway: the guarded Adam step skips the step).
+__device__ __forceinline__ float at_ds(float p, float dp, float Di) {
+  const float v = (p * 0.125f) * (dp - Di);
+#ifdef APH_EMU
+  return fminf(fmaxf(v, -65504.f), 65504.f);
+#else
+  return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+#endif
+}
 
 // One (cut, head) attention forward from LDS tiles: Qs, Ks row-major [64][64] (at_off), Vt the transposed slot-permuted image of V.
 // Wave `it` owns query tile it (16 rows); att_row0 = the head's 64 columns of the cut's first row in att [.., D]; lse_row0 likewise.
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st[jt][r] = (st[jt][r] * 0.125f) * (dp[jt][r] - Di);      // dS^T
+        for (int r = 0; r < 4; ++r) st[jt][r] = at_ds(st[jt][r], dp[jt][r], Di);      // dS^T
       const half8 d0 = pack8(st[0], st[1]), d1 = pack8(st[2], st[3]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
           // (queries >= T: Q and dO rows are zero, L2 = D = 0 -> p = 1, dS = 0; their dO^T / Q^T rows are zero)
           const float p = at_p(sq[t][r], L4[r]);
           pp[t][r] = p;
-          sq[t][r] = (p * 0.125f) * (dq[t][r] - D4[r]);     // dS
+          sq[t][r] = at_ds(p, dq[t][r], D4[r]);     // dS
         }
       }
       const half8 p0 = pack8(pp[0], pp[1]), p1 = pack8(pp[2], pp[3]);
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __rest
             dp[u] = mfma_16x16x32_f16(at_frag(Vs, jr, kd * 4 + g), of[kd], dp[u]);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) st[u][r] = (at_p(st[u][r], Li2) * 0.125f) * (dp[u][r] - Di);      // dS^T
+          for (int r = 0; r < 4; ++r) st[u][r] = at_ds(at_p(st[u][r], Li2), dp[u][r], Di);      // dS^T
         }
         const half8 df = pack8(st[0], st[1]);
 #pragma unroll
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
           for (int r = 0; r < 4; ++r) {
             const float p = at_p(sq[u][r], L4[r]);       // L4 = lse * log2 e
             pp[u][r] = p;
-            sq[u][r] = (p * 0.125f) * (dq[u][r] - D4[r]);     // dS
+            sq[u][r] = at_ds(p, dq[u][r], D4[r]);     // dS
           }
         }
         const half8 pf = pack8(pp[0], pp[1]), sf = pack8(sq[0], sq[1]);

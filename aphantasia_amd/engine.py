@@ -91,7 +91,8 @@ class Engine:
         # static loss scale of the fp16 backward with back-off: an overflowed step (NaN / inf gradient) is skipped on the
         # device (aph_adam_step_guarded); the host looks at the skip counter every GUARD_EVERY steps and halves the scale
         self.loss_scale = float(LOSS_SCALE if loss_scale is None else loss_scale)
-        self._guard_seen, self._guard_host, self._guard_ev, self._guard_rebase_until = 0, None, None, -1
+        self._guard_seen, self._guard_host, self._guard_ev = 0, None, None
+        self._guard_floor, self._floor_host, self._floor_ev = 0, None, None      # skip count at the last reset_params (device snapshot)
         self.enforce = float(enforce)                               # clip_fft.py:271-275
         # aest = (weight [D] or [1,D], bias, strength): `loss -= 0.001 * strength * (enc @ w + b).mean()` (clip_fft.py:255-256,
         # utils.py:402-413: the LAION linear aesthetic predictor on the raw encodings)
@@ -214,12 +215,21 @@ class Engine:
                     if t is not None:
                         t.zero_()
                 self._state['step'][0] = 0
-                # skipped-step bookkeeping belongs to the optimiser instance that just ended: a skip reported (up to GUARD_EVERY steps
-                # late) after this point must not be subtracted from the NEW frame's step counter.  The device counter keeps counting
-                # (bench.py reads it); what is re-based is the host's view of it.  The window closes by itself: the counter value read
-                # at call c was copied back at call c - GUARD_EVERY, so a skip of the OLD optimiser can surface in the two read-backs
-                # that follow the reset and in none after them -- a later (genuine) skip of the new frame is subtracted as usual.
-                self._guard_rebase_until = self._calls + 2 * self.GUARD_EVERY
+                # skipped-step bookkeeping belongs to the optimiser instance that just ended: a skip counted on the device BEFORE this
+                # point must not be subtracted from the new frame's step counter, one counted after it must.  The boundary is a
+                # snapshot of the device counter taken HERE in stream order (copied back asynchronously, read in _check_overflow),
+                # not a window of calls: a genuine overflow of the new frame right after the reset is still accounted for.
+                if self.params.is_cuda:
+                    if self._floor_host is None:
+                        self._floor_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    elif self._floor_ev is not None:
+                        self._floor_ev.synchronize()          # (the previous snapshot has landed before its buffer is reused)
+                        self._guard_floor = max(self._guard_floor, int(self._floor_host[0]))
+                    self._floor_host.copy_(self.guard[:1], non_blocking=True)
+                    self._floor_ev = torch.cuda.Event()
+                    self._floor_ev.record()
+                else:
+                    self._guard_floor = int(self.guard[0])
 
     def set_prev_enc(self, enc_rows=None, active=True):
         """--expand: make the encodings of the step just taken (this rank's rows; default: this engine's own) the per-cut
@@ -400,8 +410,12 @@ class Engine:
         if count > self._guard_seen:
             # a skipped step is no optimiser step: torch.optim's state['step'] would not have advanced either (not carried across a
             # reset_params: those skips belonged to the previous frame's optimiser)
-            if self._calls > self._guard_rebase_until:
-                self._state['step'][0] = max(self._state['step'][0] - (count - self._guard_seen), 0)
+            if self._floor_ev is not None:
+                self._floor_ev.synchronize()
+                self._guard_floor, self._floor_ev = max(self._guard_floor, int(self._floor_host[0])), None
+            mine = count - max(self._guard_seen, self._guard_floor)          # skips of the CURRENT optimiser instance among the new ones
+            if mine > 0:
+                self._state['step'][0] = max(self._state['step'][0] - mine, 0)
             self._guard_seen = count
             self.loss_scale = max(self.loss_scale * 0.5, 1.0)
             self._graphs = None

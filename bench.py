@@ -61,6 +61,9 @@ def parse():
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-legs', action='store_true', help='skip the -tf none and with-save legs (N = 1 only has them)')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    p.add_argument('--f16', action='store_true', help='f16 operands on EVERY ViT GEMM (the opt-out of the split-precision forward): ~7 %% faster, '
+                                                     'holds the stress-weight loss curve at 2e-3 instead of 1e-3')
+    p.add_argument('--reps', type=int, default=3, help='repetitions of the timed block of --steps steps (value = the median block)')
     p.add_argument('--vit-path', default=None, help='measurement switch: comma list of name=int pairs handed to the library\'s test hooks '
                                                     '(rs: aph_gemm_set_rs, fused: aph_vit_set_fused_max_rows, ws: aph_gemm_set_ws_min_tiles)')
     a = p.parse_args()
@@ -303,12 +306,6 @@ def _spawned_rank(local_rank, world, port):
 def main():
     a = parse()
     cfg = a.cfg
-    # watchdog: dump every thread's Python stack and exit if the run is still going after N seconds (APH_BENCH_WATCHDOG=N; multi-rank runs
-    # default to 900 s -- a rank stuck in a collective should fail loudly with a stack, not sit in the launcher's timeout)
-    wd = os.environ.get('APH_BENCH_WATCHDOG') or ('900' if (a.gpus > 1 or int(os.environ.get('WORLD_SIZE', 1)) > 1) else '')
-    if wd and int(wd) > 0:
-        import faulthandler
-        faulthandler.dump_traceback_later(int(wd), exit=True)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU), exactly what torchrun would have done
         have = torch.cuda.device_count()
@@ -320,6 +317,18 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # watchdog (rank processes only, never the spawning parent): dump every thread's Python stack and exit if the TIMED multi-rank section is
+    # still going after N seconds (APH_BENCH_WATCHDOG=N, default 900 for world > 1; 0 = off) -- a rank stuck in a collective should fail
+    # loudly with a stack, not sit in the launcher's timeout.  It is cancelled once the timed section and the rank checks are through, so a
+    # slow but healthy run (legs, CPU baseline) is never killed by it.
+    wd_s = os.environ.get('APH_BENCH_WATCHDOG', '900' if world > 1 else '0')
+    try:
+        wd = max(int(wd_s), 0)
+    except ValueError:
+        raise SystemExit('APH_BENCH_WATCHDOG=%r is not a number of seconds' % wd_s)
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     # debugging aid for single-GPU boxes: APH_BENCH_BACKEND=gloo puts every rank on cuda:0 and reduces through the host
@@ -389,6 +398,7 @@ def main():
             kw.update(param_kind='dwt', dwt=image_f.synth)
         else:
             leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
+        kw['precise'] = not a.f16       # headline mode: the split-precision forward (the mode that holds north_star's 1e-3 on stress weights)
         kw.update(extra)
         e1 = Engine(leaf, h, w, model, S_eff, [(target, -1.0)], **kw)
         e2 = Engine(leaf, h, w, model2, S_eff, [(target2, -1.0)], state=e1.state(), **kw) if dualmod is not None else None
@@ -434,7 +444,10 @@ def main():
         return dt
 
     eng, eng_b = make(cfg['transform'], S)
-    dt = timed(eng, eng_b, a.steps, a.warmup)
+    # the timed block of exactly --steps steps, --reps times back to back (warm-up before the first only); `value` is the MEDIAN block --
+    # one block of 20 steps is 0.12 s, and box-to-box / run-to-run spread of a few percent is of the order of the effects reported here
+    dts = [timed(eng, eng_b, a.steps, a.warmup if r == 0 else 0) for r in range(max(a.reps, 1))]
+    dt = sorted(dts)[len(dts) // 2]
     loss = eng.global_loss()
     # multi-rank sanity, outside the timed region: the communicator's own rank count, and the parameters bit-identical on every rank
     # after warm-up + K steps (a 64-bit hash of the bit patterns: every rank applied the same all-reduced gradient)
@@ -449,6 +462,9 @@ def main():
         params_identical = all(bool(torch.equal(hs[0], x)) for x in hs[1:])
         if ranks_seen != world or not params_identical:
             raise SystemExit('bench.py: rank check failed (communicator sees %d of %d ranks, parameters identical across ranks: %s)' % (ranks_seen, world, params_identical))
+    if wd > 0:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     skipped = int(eng.guard[0])          # steps whose fp16 backward overflowed and were skipped by the guarded Adam: must be 0 for a valid line
     flop_step = 2 * S * F_IMG[cfg['model']] / 1e12
     if dualmod is not None:     # the schedule's mix of B/32 and B/16 steps over the timed region
@@ -481,10 +497,13 @@ def main():
             traffic, tsrc, stale, tmatch = (None, None, None, None)
             if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1:
                 traffic, tsrc, stale, tmatch = pmc_traffic('r[0-9][0-9]_pmc_hbm_traffic*.json')
-            roof = dict(bound='mfma', kernel='aph::gemm_ws_kernel<*> / aph::gemm_f16_kernel<*> / aph::gemm8_f16_kernel<*>', achieved=achieved, peak=PEAK_TF,
+            roof = dict(bound='mfma', kernel='aph::gemm_ws_kernel<*> / aph::gemm_f16_kernel<*> / aph::gemm_sk_kernel<*> (the ViT GEMM family)', achieved=achieved, peak=PEAK_TF,
                         unit='TFLOP/s', frac=achieved / PEAK_TF, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
                         traffic_source=tsrc, traffic_stale=stale, traffic_match=tmatch, launches_per_step=n_t // nprof,
                         avg_launch_us=ms_t * 1e3 / n_t, flops_per_launch=fl_t / n_t, gemm_ms_per_step=ms_t / nprof,
+                        executed_gemm_tflop_per_step=fl_t / nprof / 1e12,
+                        executed_note='FLOPs of the GEMM launches as executed (the last block runs its out-proj / MLP on the class rows only, which '
+                                      'algorithmic_tflop_per_step -- the survey\'s definition -- still counts in full)',
                         step_frac=flop_step * (a.steps / dt) / PEAK_TF,
                         step_frac_note='algorithmic_tflop_per_step x steps/s / peak (whole step, every kernel and gap included)',
                         peak_measured=mfma_peak(lib, dev))
@@ -516,11 +535,29 @@ def main():
             shutil.rmtree(tmpdir, ignore_errors=True)
 
     if legs is not None and a.config == 'c2':
-        # the opt-in split-precision forward (clip_fft.py --precise / aph_vit_forward_hilo): what closing the stress-weight parity gap costs
-        e_pr, e_prb = make(cfg['transform'], S, precise=True)
+        # the reference's own draw order (utils.py:222-251 per cut on torch's / numpy's global generators: what every --seed run of the CLI
+        # uses so that its crop tables reproduce the reference's) instead of the vectorised draws: same distributions, more host Python
+        e_r, e_rb = make(cfg['transform'], S, rng='reference')
+        dtr = timed(e_r, e_rb, a.steps, a.warmup)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            e_r.draw()
+        host_ref = (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eng.draw()
+        host_bulk = (time.perf_counter() - t0) / 10
+        legs['rng_reference'] = dict(value=a.steps / dtr, unit='steps/s', ms_per_step=1e3 * dtr / a.steps, host_draw_ms=1e3 * host_ref, host_draw_ms_bulk=1e3 * host_bulk,
+                                     note="rng='reference': the reference's per-cut draw order (every --seed run); `value` uses the vectorised draws (rng='bulk')")
+        del e_r, e_rb
+        # the other precision mode, same workload as `value`: what the split-precision forward costs / what dropping it buys
+        e_pr, e_prb = make(cfg['transform'], S, precise=bool(a.f16))
         dtpr = timed(e_pr, e_prb, a.steps, a.warmup)
-        legs['precise'] = dict(value=a.steps / dtpr, unit='steps/s', ms_per_step=1e3 * dtpr / a.steps, skipped_steps=int(e_pr.guard[0]),
-                               note='--precise: patch-embedding and QKV GEMMs on hi + lo f16 activation pairs (twice their K); same workload as `value`')
+        legs['f16_everywhere' if not a.f16 else 'split_precision'] = dict(
+            value=a.steps / dtpr, unit='steps/s', ms_per_step=1e3 * dtpr / a.steps, skipped_steps=int(e_pr.guard[0]),
+            note=('--f16 / clip_fft.py --fast-f16: f16 operands on every ViT GEMM (what the reference itself runs CLIP at on a GPU); stress-weight '
+                  '60-step loss curve within 2e-3 (tests/test_gpu_parity_configs.py::test_stress_weights_loss_curve_60steps_f16_everywhere)') if not a.f16 else
+                 'the default mode: patch-embedding and QKV GEMMs on hi + lo f16 activation pairs (twice their K); stress-weight curve within 1e-3')
         del e_pr, e_prb
         # strong-scaling ceiling without an 8-GPU node: this GPU's step time at the per-rank shard sizes of 2 / 4 / 8 ranks (the collective
         # and its overlap are NOT in these numbers: 11 MB all-reduce per step)
@@ -578,7 +615,14 @@ def main():
             'metric': 'optimization steps/sec @%dx%d %s samples=%d' % (w, h, cfg['model'], cfg['samples']),
             'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f16 (MFMA operands, fp32 accumulate; fp32 synth/sampler/loss/Adam)', 'data': 'synthetic',
+            'dtype': ('f16 (MFMA operands, fp32 accumulate; fp32 synth/sampler/loss/Adam)' if a.f16 else
+                      'f16 MFMA operands with hi + lo split activations on the patch-embedding / QKV GEMMs, fp32 accumulate; fp32 synth/sampler/loss/Adam'),
+            'precision': dict(mode='f16_everywhere' if a.f16 else 'split',
+                              loss_curve_tolerance=2e-3 if a.f16 else 1e-3,
+                              pinned_by='tests/test_gpu_parity_configs.py::test_stress_weights_loss_curve_60steps_' + ('f16_everywhere' if a.f16 else 'headline_mode_vs_oracle_fixture'),
+                              note='north_star: loss-vs-step curve within 1e-3 of the CPU reference; the headline mode is the one that holds it on weights with realistic dynamic range'),
+            'repeats': dict(n=len(dts), steps_per_s=sorted(a.steps / t for t in dts), median=a.steps / dt, block_s=dts),
+            'data': 'synthetic',
             'config': {'workload': '%s: %dx%d %s parameteriser, %s%s, --samples %d -> %d effective cuts, -tf %s, sim %s, '
                                    'Adam(lr .05, b1 0), per-step image save off' % (a.config.upper(), w, h, kind, cfg['model'],
                                                                                     ' + ViT-B/16 every %d steps (--dualmod)' % dualmod if dualmod else '',

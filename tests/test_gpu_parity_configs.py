@@ -158,20 +158,20 @@ def test_c2_loss_curve_32cuts_200steps_vs_oracle_fixture():
     assert rms < 0.03, rms
 
 
-def test_stress_weights_loss_curve_60steps_vs_oracle_fixture():
-    """`stress_visual_weights` (LN gains 0.2-10, massive residual channels, peaky attention), 32 cuts, 60 free-running steps, DEFAULT path
-    (f16 MFMA operands everywhere, as the reference itself runs CLIP on a GPU).  Round 4, with f16-representable weights on both sides (as
+def test_stress_weights_loss_curve_60steps_f16_everywhere():
+    """`stress_visual_weights` (LN gains 0.2-10, massive residual channels, peaky attention), 32 cuts, 60 free-running steps, the OPT-OUT mode
+    (`bench.py --f16` / `clip_fft.py --fast-f16`: f16 MFMA operands everywhere, as the reference itself runs CLIP on a GPU).  Round 4, with f16-representable weights on both sides (as
     real checkpoints are): max |d loss| 1.0e-3, past 1e-3 for a few steps around step 12 -- the fp32 oracle with EVERY HIP f16 rounding
     emulated lands at 8e-4 on this trajectory (tools/precision_attribution.py, profiles/r04_precision_attribution.txt), and any single one of
-    them moves it by 0.3-8e-4.  What holds 1e-3 here is the opt-in split-precision forward (next test); the default path is asserted at 2e-3."""
+    them moves it by 0.3-8e-4.  What holds 1e-3 here is the split-precision forward, the default of bench.py and the CLI (next test); this mode is asserted at 2e-3."""
     worst, first, rms, got = _curve('c2_s32_stress')
     print('stress weights, 32 cuts, 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f' % (worst, first, rms))
     assert first is None or first >= 8, first
     assert worst < 2e-3 and rms < 0.05 and np.isfinite(got).all(), (worst, rms)
 
 
-def test_stress_weights_loss_curve_60steps_precise_mode_vs_oracle_fixture():
-    """The same stress-weight curve with the opt-in SPLIT-PRECISION forward (Engine(precise=True) / clip_fft.py --precise /
+def test_stress_weights_loss_curve_60steps_headline_mode_vs_oracle_fixture():
+    """The same stress-weight curve in the HEADLINE mode of bench.py and the CLI: the SPLIT-PRECISION forward (Engine(precise=True) /
     aph_vit_forward_hilo: the cuts and every block's first LayerNorm output as hi + lo f16 pairs -- the two roundings
     profiles/r04_precision_attribution.txt puts at the top): north_star's 1e-3 over all 60 steps."""
     worst, first, rms, got = _curve('c2_s32_stress', precise=True)
