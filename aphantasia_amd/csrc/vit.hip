@@ -43,7 +43,7 @@ struct aph_vit {
   std::vector<Layer> layers;
   float *x0 = nullptr, *x_last = nullptr;
   half_t *h = nullptr, *gact = nullptr;
-  float* dx = nullptr;
+  float *dx = nullptr, *dx2 = nullptr;      // fp32 residual-stream gradient (dx2: the second buffer of the fused backward's hand-over)
   float* delta = nullptr;              // attention backward row dots dO_i . O_i (T > 64 path)
   half_t *dx16 = nullptr, *du = nullptr, *dh = nullptr, *datt = nullptr, *dqkv = nullptr, *dx0_16 = nullptr;
   SplitKSpace sk;                      // split-K partials of the small-M GEMMs (per-rank shards, class-row GEMMs)
@@ -88,7 +88,7 @@ void carve(aph_vit* v, char* base, size_t* total) {
   }
   v->x0 = c.take<float>(Mx * D); v->x_last = c.take<float>(Mx * D);
   v->h = c.take<half_t>(Mx * 2 * D); v->gact = c.take<half_t>(Mx * 4 * D);      // h: [hi | lo] rows in the split-precision forward
-  v->dx = c.take<float>(Mx * D);
+  v->dx = c.take<float>(Mx * D); v->dx2 = c.take<float>(Mx * D);
   v->delta = c.take<float>((size_t)v->max_batch * v->heads * T);
   v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
   v->datt = c.take<half_t>(Mx * D); v->dqkv = c.take<half_t>(Mx * 3 * D); v->dx0_16 = c.take<half_t>(Mx * D);
@@ -150,6 +150,11 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
 #endif
 int g_fused_max_rows = APH_VIT_FUSED_MAX_ROWS_DEFAULT;
 inline bool vit_fused(const aph_vit* v, int S) { return v->T <= AT_T && v->D <= 1024 && (long long)S * v->T <= g_fused_max_rows; }
+// the (cut, head) kernel with the attention behind the QKV GEMM holds 120 KiB of LDS -- one workgroup per CU -- so it only pays while all
+// S x heads workgroups run at once (288 of them on 256 CUs take two rounds: 33 against 21 us at 24 cuts); otherwise LayerNorm + QKV go
+// through the flat-row kernel and the attention stays a launch of its own.  0 = never, 1 = automatic, 2 = always (tests).
+int g_fused_attn = 1;
+inline bool vit_fused_attn(const aph_vit* v, int S) { return g_fused_attn == 2 || (g_fused_attn == 1 && S * v->heads <= gemm_persistent_wgs()); }
 
 void launch_qkv_attn(aph_vit* v, const Layer& l, int S, hipStream_t st) {
   const int nv = v->D / 256;
@@ -162,6 +167,16 @@ void launch_qkv_attn(aph_vit* v, const Layer& l, int S, hipStream_t st) {
     case 2: go(std::integral_constant<int, 2>{}); break;
     case 3: go(std::integral_constant<int, 3>{}); break;
     default: go(std::integral_constant<int, 4>{}); break;
+  }
+}
+template <class Epi>
+void launch_lnbwd_gemm(aph_vit* v, const half_t* dy, const float* x, const float* g, const float* res, float* out32, int res_T, int M, const half_t* Wt,
+                       int N, Epi epi, hipStream_t st) {
+  switch (v->D / 256) {
+    case 1: launch_blk_lnbwd_gemm<1, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    case 2: launch_blk_lnbwd_gemm<2, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    case 3: launch_blk_lnbwd_gemm<3, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    default: launch_blk_lnbwd_gemm<4, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
   }
 }
 template <class Epi>
@@ -382,8 +397,11 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
-    if (blk) {
+    if (blk && vit_fused_attn(v, S)) {
       vtimed(v, 2.0 * M * 3 * D * D + 4.0 * S * v->heads * T * T * 64, st, [&] { launch_qkv_attn(v, l, S, st); });
+    } else if (blk) {
+      vtimed(v, 2.0 * M * 3 * D * D, st, [&] { launch_ln_gemm(v, l.x_in, 1, M, l.ln1_g, l.ln1_b, l.w_qkv, 3 * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st); });
+      launch_attn_fwd(attn_args(v, l, S), st);
     } else {
       if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
       vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
@@ -432,18 +450,37 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   if (!fuse) zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
+  // fused backward (vit_block.h): a block's closing ln_1 backward is not launched; it runs as the prologue of the NEXT (lower) block's fc2
+  // dgrad -- `pending` carries it over: dy = v->dh, LayerNorm input = the upper block's x_in, residual = v->dx (only the rows % res_T == 0)
+  const bool blk = vit_fused(v, S);
+  bool pending = false;
+  int pending_res_T = 0;
   for (int li = v->L - 1; li >= 0; --li) {
     Layer& l = v->layers[li];
     const bool cls_only = li + 1 == v->L;          // see aph_vit_forward: the last block's MLP / out-proj saw class rows only
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
     if (cls_only) zero_fill_async(v->datt, sizeof(half_t) * (size_t)M * D, st);   // no gradient into the other rows' attention output
-    vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+    const float* res2 = v->dx;                      // residual of this block's ln_2 backward
+    if (pending) {
+      const Layer& up = v->layers[li + 1];
+      vtimed(v, 2.0 * M * 4 * D * D, st, [&] {
+        launch_lnbwd_gemm(v, v->dh, up.x_in, up.ln1_g, v->dx, v->dx2, pending_res_T, M, l.w_fc2T, 4 * D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+      });
+      res2 = v->dx2;
+      pending = false;
+    } else {
+      vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
+    }
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
-    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx, v->dx, v->dx16, Mr, T, st, rs);
+    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, res2, v->dx, v->dx16, Mr, T, st, rs);
     vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
     launch_attn_bwd(attn_args(v, l, S), st);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
-    if (fuse && li == 0)      // ln_1 backward and ln_pre backward as one kernel: writes the patch rows of dx0_16 only
+    if (blk && li > 0) {      // deferred into block li - 1's first launch
+      pending = true;
+      pending_res_T = (fuse && cls_only) ? T : 0;
+    }
+    else if (fuse && li == 0)      // ln_1 backward and ln_pre backward as one kernel: writes the patch rows of dx0_16 only
       launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, nullptr, v->dx0_16, M, T, st, 1, cls_only ? T : 0, v->x0, v->ln_pre_g);
     else
       launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st, 1, (fuse && cls_only) ? T : 0);
@@ -502,6 +539,14 @@ int aph_vit_set_fuse_ln(int on) {
 int aph_vit_set_fused_max_rows(int rows) {
   const int prev = g_fused_max_rows;
   g_fused_max_rows = rows < 0 ? 0 : rows;
+  return prev;
+}
+
+// the (cut, head) LayerNorm + QKV + attention kernel inside the fused forward: 0 = never, 1 = while S x heads workgroups fit the chip in one
+// round (default), 2 = always.  Returns the previous value.
+int aph_vit_set_fused_attn(int mode) {
+  const int prev = g_fused_attn;
+  g_fused_attn = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return prev;
 }
 

@@ -10,8 +10,10 @@
 //                         backward), att and lse in the unfused layouts;
 //   blk_ln_gemm_kernel    one workgroup per (64 rows, 256 columns): LayerNorm prologue + A-resident GEMM + any apply8 epilogue (fc1 +
 //                         QuickGELU).
-// Forward per block: 4 launches (this pair + the two narrow GEMMs with their residual epilogues) instead of 7; the saved activations keep
-// their layouts, so the backward may run fused or not independently.
+//   blk_lnbwd_gemm_kernel the backward counterpart: the LayerNorm input-gradient of the block ABOVE (ln_1) as the prologue of this block's fc2
+//                         dgrad GEMM with the QuickGELU-derivative epilogue.
+// Forward per block: 4-5 launches instead of 7, backward 6 instead of 7; the saved activations keep their layouts, so the two directions
+// switch independently.
 #pragma once
 #include "vit_gemm_rs.h"
 #include "vit_ops.h"
@@ -21,47 +23,76 @@ namespace aph {
 
 __device__ __forceinline__ half4 blk_h4(const f32x4& v) { return half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
 
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in all of them: quad_perm x2, row_half_mirror, row_mirror -- four
+// VALU instructions, no LDS round trip (__shfl_xor compiles to ds_bpermute_b32 here: ~100 clocks per step, six dependent steps per
+// wave-wide sum, which made the first version of this prologue a 10 us chain: profiles/r05_kernel_stats_s26_fused_fwd_v1.csv)
+template <int CTRL>
+__device__ __forceinline__ float blk_dpp(float v) {
+#ifdef APH_EMU
+  return v;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#ifdef APH_EMU
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+#else
+  v += blk_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += blk_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += blk_dpp<0x141>(v);     // row_half_mirror
+  v += blk_dpp<0x140>(v);     // row_mirror
+  return v;
+#endif
+}
+// nothing is scheduled across this point (pins the order "all loads first": the scheduler otherwise sinks them to their uses to save registers)
+__device__ __forceinline__ void blk_sched_fence() {
+#ifndef APH_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // LayerNorm of 64 rows into the resident A block: rows r < nrows of x (row pitch xstride elements), the others as zeros.  Wave w takes the
-// rows w, w + 4, ...: all sixteen are requested before the first is reduced (rows past nrows re-read the last valid one: no load sits
-// behind a condition).  Element d of row r goes to k-step d >> 5, chunk (d >> 3) & 3 of the image (rs_swz placement).
+// rows 16 w .. 16 w + 15, FOUR AT A TIME: a row belongs to the 16 lanes of a DPP row (lane >> 4), a lane holds the elements
+// d = 64 i + 4 (lane & 15) + 0..3 of it (16 lanes x 16 bytes = 256 contiguous bytes per row and load).  All of the wave's rows are requested
+// before the first is reduced (rows past nrows re-read the last valid one: no load sits behind a condition).  Element d of row r goes to
+// k-step d >> 5, chunk (d >> 3) & 3 of the image (rs_swz placement).
 template <int NV>
 __device__ __forceinline__ void blk_ln_fill(char* a_img, const float* __restrict__ x, size_t xstride, int nrows, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, int wave, int lane) {
-  constexpr int D = 256 * NV;
-  f32x4 v[16][NV];
+  constexpr int D = 256 * NV, NE = D / 64;               // f32x4 pieces per lane and row
+  const int c16 = lane & 15, sub = lane >> 4;
+  f32x4 v[4][NE];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int r = wave + 4 * j, rr = r < nrows ? r : nrows - 1;
+  for (int p = 0; p < 4; ++p) {
+    const int r = 16 * wave + 4 * p + sub, rr = r < nrows ? r : nrows - 1;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[j][i] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * xstride + i * 256 + lane * 4);
+    for (int i = 0; i < NE; ++i) v[p][i] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * xstride + i * 64 + c16 * 4);
   }
-  f32x4 g[NV], b[NV];
+  blk_sched_fence();
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    g[i] = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
-    b[i] = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int r = wave + 4 * j;
+  for (int p = 0; p < 4; ++p) {
+    const int r = 16 * wave + 4 * p + sub;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) s += v[j][i][0] + v[j][i][1] + v[j][i][2] + v[j][i][3];
-    const float mean = wave_sum(s) * (1.0f / D);
+    for (int i = 0; i < NE; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
+    const float mean = row16_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
+    for (int i = 0; i < NE; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float c = v[j][i][e] - mean; q += c * c; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + kLnEps);
+      for (int e = 0; e < 4; ++e) { const float c = v[p][i][e] - mean; q += c * c; }
+    const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + kLnEps);
     const bool live = r < nrows;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < NE; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 64 + c16 * 4), b = *reinterpret_cast<const f32x4*>(beta + i * 64 + c16 * 4);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = live ? (v[j][i][e] - mean) * rstd * g[i][e] + b[i][e] : 0.f;
-      const int ks = i * 8 + (lane >> 3), c = (lane >> 1) & 3;
-      *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (lane & 1) * 8) = blk_h4(o);
+      for (int e = 0; e < 4; ++e) o[e] = live ? (v[p][i][e] - mean) * rstd * g[e] + b[e] : 0.f;
+      const int ks = 2 * i + (c16 >> 3), c = (c16 >> 1) & 3;
+      *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (c16 & 1) * 8) = blk_h4(o);
     }
   }
 }
@@ -90,6 +121,7 @@ __global__ __launch_bounds__(256) void blk_qkv_attn_kernel(const float* __restri
     woff[nt] = ((unsigned)(nt * D + h * 64 + 16 * wave + L.lrow) * (unsigned)D + L.lpc * 8) * 2u;
   ARStream<3, PD> W;
   W.template prefetch<C::NKS>(Bb, woff);                             // the first weight k-steps fly during the LayerNorm
+  blk_sched_fence();
   blk_ln_fill<NV>(smem, x + (size_t)s * T * D, D, T, gamma, beta, wave, lane);
   __syncthreads();
   f32x4 acc[4][3];
@@ -154,6 +186,7 @@ __global__ __launch_bounds__(256) void blk_ln_gemm_kernel(const float* __restric
   for (int nt = 0; nt < NT; ++nt) woff[nt] = ((unsigned)(n0 + 4 * NT * (L.lrow >> 2) + 4 * nt + (L.lrow & 3)) * (unsigned)D + L.lpc * 8) * 2u;
   ARStream<NT, PD> W;
   W.template prefetch<NKS>(Bb, woff);
+  blk_sched_fence();
   const int nrows = M - m0 < C::BM ? M - m0 : C::BM;
   blk_ln_fill<NV>(smem, x + (size_t)m0 * xs * D, (size_t)xs * D, nrows, gamma, beta, wave, lane);
   __syncthreads();
@@ -171,6 +204,127 @@ __global__ __launch_bounds__(256) void blk_ln_gemm_kernel(const float* __restric
       for (int j = 0; j < NT / 2; ++j) epi.apply8(m, n0 + 4 * NT * (lane >> 4) + 8 * j, acc[mt][2 * j], acc[mt][2 * j + 1]);
     }
   }
+}
+
+// ---- LayerNorm input-gradient + wide GEMM + apply8 epilogue (backward: ln_1 of the block above in front of this block's fc2 dgrad) ------
+// Prologue: g = [res +] rstd (gamma dy - mean(gamma dy) - xhat mean(gamma dy xhat)) for 64 rows (the arithmetic of ln_bwd_kernel; x = the
+// LayerNorm's input, statistics recomputed), f16(g) into the resident A block, and -- from the workgroups of column group 0 only -- g in
+// fp32 to out32 (a buffer OTHER than res: the other column groups still read res).  res_T > 0: only the rows with row % res_T == 0 have a
+// residual (see ln_bwd_kernel).  Rows in two batches of eight per wave (x, dy and res of a batch in flight together).
+template <int NV>
+__device__ __forceinline__ void blk_lnbwd_fill(char* a_img, const half_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                               const float* __restrict__ res, float* __restrict__ out32, int m0, int nrows, int res_T, int wave, int lane) {
+  constexpr int D = 256 * NV, NE = D / 64;
+  const int c16 = lane & 15, sub = lane >> 4;
+#pragma unroll
+  for (int b0 = 0; b0 < 4; b0 += 2) {
+    f32x4 xv[2][NE], rv[2][NE];
+    half4 dv[2][NE];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * wave + 4 * (b0 + p) + sub, rr = r < nrows ? r : nrows - 1;
+      const size_t row = (size_t)(m0 + rr) * D;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        xv[p][i] = *reinterpret_cast<const f32x4*>(x + row + i * 64 + c16 * 4);
+        dv[p][i] = *reinterpret_cast<const half4*>(dy + row + i * 64 + c16 * 4);
+        rv[p][i] = *reinterpret_cast<const f32x4*>(res + row + i * 64 + c16 * 4);
+      }
+    }
+    blk_sched_fence();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * wave + 4 * (b0 + p) + sub;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) s += (xv[p][i][0] + xv[p][i][1]) + (xv[p][i][2] + xv[p][i][3]);
+      const float mean = row16_sum(s) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[p][i][e] -= mean; q += xv[p][i][e] * xv[p][i][e]; }
+      const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + kLnEps);
+      f32x4 gd[NE];
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 64 + c16 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xv[p][i][e] *= rstd;                                   // xhat
+          gd[i][e] = (float)dv[p][i][e] * g[e];
+          sg += gd[i][e];
+          sgx += gd[i][e] * xv[p][i][e];
+        }
+      }
+      sg = row16_sum(sg) * (1.0f / D);
+      sgx = row16_sum(sgx) * (1.0f / D);
+      const bool live = r < nrows;
+      const bool has_res = res_T == 0 || (m0 + r) % res_T == 0;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rstd * (gd[i][e] - sg - xv[p][i][e] * sgx);
+          if (has_res) o[e] += rv[p][i][e];
+          if (!live) o[e] = 0.f;
+        }
+        if (out32 && live) *reinterpret_cast<f32x4*>(out32 + (size_t)(m0 + r) * D + i * 64 + c16 * 4) = o;
+        const int ks = 2 * i + (c16 >> 3), c = (c16 >> 1) & 3;
+        *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (c16 & 1) * 8) = blk_h4(o);
+      }
+    }
+  }
+}
+
+template <int NV, int PD, class Epi>
+__global__ __launch_bounds__(256) void blk_lnbwd_gemm_kernel(const half_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ res, float* __restrict__ out32, int res_T, int M,
+                                                             const half_t* __restrict__ Wt, int N, Epi epi) {
+  constexpr int D = 256 * NV, NKS = 8 * NV, NT = 4;
+  using C = GemmAR<NT>;
+  APH_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  int tm, tn;
+  ar_tile((M + C::BM - 1) / C::BM, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN + wave * 16 * NT;
+  const RSLane L(lane);
+  const char* Bb = reinterpret_cast<const char*>(Wt);
+  unsigned woff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) woff[nt] = ((unsigned)(n0 + 4 * NT * (L.lrow >> 2) + 4 * nt + (L.lrow & 3)) * (unsigned)D + L.lpc * 8) * 2u;
+  ARStream<NT, PD> W;
+  W.template prefetch<NKS>(Bb, woff);
+  blk_sched_fence();
+  const int nrows = M - m0 < C::BM ? M - m0 : C::BM;
+  blk_lnbwd_fill<NV>(smem, dy, x, gamma, res, tn == 0 ? out32 : nullptr, m0, nrows, res_T, wave, lane);
+  __syncthreads();
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  W.template run<NKS>(acc, smem, smem + NKS * 4096 + wave * (2 * C::WIMG), Bb, woff, L);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + 16 * mt + (lane & 15);
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) epi.apply8(m, n0 + 4 * NT * (lane >> 4) + 8 * j, acc[mt][2 * j], acc[mt][2 * j + 1]);
+    }
+  }
+}
+
+template <int NV, int PD, class Epi>
+inline void launch_blk_lnbwd_gemm(const half_t* dy, const float* x, const float* gamma, const float* res, float* out32, int res_T, int M, const half_t* Wt,
+                                  int N, Epi epi, hipStream_t st) {
+  using C = GemmAR<4>;
+  const int smem = C::smem(256 * NV);
+  APH_ALLOW_SMEM((blk_lnbwd_gemm_kernel<NV, PD, Epi>), smem);
+  APH_LAUNCH((blk_lnbwd_gemm_kernel<NV, PD, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(256), smem, st, dy, x, gamma, res, out32, res_T, M,
+             Wt, N, epi);
 }
 
 template <int NV, int PD, class Epi>

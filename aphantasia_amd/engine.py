@@ -80,10 +80,13 @@ class Engine:
         # hipGraph replay only saves host time (on the 128-core GPU box eager launches measure the same step time at every
         # shard size).  Round 1 saw NaN gradients from replays next to eager work + device synchronizes; the cause turned out to
         # be the graph's MEMSET nodes (captured hipMemsetAsync), which this runtime mis-orders -- the step now zero-fills with
-        # kernels (csrc/aph_device.h zero_fill_async; repro: tools/exp/frame_debug3.py on the commit before).  Multi-rank runs
-        # still launch eagerly by default because a graph with an RCCL node could only be exercised at world size 1 here.
-        if world > 1 and not (comm is not None and os.environ.get('APH_MULTIRANK_GRAPH') == '1'):
-            use_graph = False          # APH_MULTIRANK_GRAPH=1: the whole step INCLUDING the RCCL all-reduce and Adam as one graph
+        # kernels (csrc/aph_device.h zero_fill_async; repro: tools/exp/frame_debug3.py on the commit before).
+        # Multi-rank: with a direct RCCL communicator the whole step INCLUDING the all-reduce and Adam is one graph too (a shard's step
+        # is ~230 launches of 5-15 us: eager launches there are host-bound) -- behind a ONE-TIME self-check at capture (_capture: the
+        # replay must reproduce an eager step bit for bit on every rank, else the engine stays eager and says so).  Through
+        # torch.distributed (the gloo / CPU test path) the collective cannot be a graph node: eager.
+        if world > 1 and comm is None:
+            use_graph = False
         self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
@@ -428,11 +431,52 @@ class Engine:
         torch.cuda.synchronize()
         self._vit_handle = self.visual.handle
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._enqueue_grad(None)
-            if self._reduce:
-                self._all_reduce()         # (only with a direct RCCL comm: the collective is a node of the step's graph)
-            self._enqueue_adam()
+        try:
+            with torch.cuda.graph(g1):
+                self._enqueue_grad(None)
+                if self._reduce:
+                    self._all_reduce()         # (only with a direct RCCL comm: the collective is a node of the step's graph)
+                self._enqueue_adam()
+        except Exception as e:                 # e.g. a collective library that refuses stream capture: stay eager, loudly
+            if self.world == 1:
+                raise
+            print(' rank %d: capturing the step with its all-reduce into a hipGraph failed (%s): multi-rank steps stay eager' % (self.rank, e), flush=True)
+            self.use_graph, self._graphs = False, None
+            return
+        if self.world > 1 and not getattr(self, '_graph_checked', False):
+            # one-time self-check: ONE eager step and ONE replay from the same state and the same (already uploaded) step inputs must
+            # leave the same bits in the parameters, on every rank
+            state = [t for t in (self.params, self.m, self.v, self.vmax, self.guard) if t is not None]
+            snap = [t.detach().clone() for t in state]
+
+            def restore():
+                with torch.no_grad():
+                    for t, c in zip(state, snap):
+                        t.copy_(c)
+            try:
+                self._enqueue_grad(None)
+                self._all_reduce()
+                self._enqueue_adam()
+                ref = self.params.detach().clone()
+                restore()
+                g1.replay()
+                same = torch.equal(ref, self.params.detach())
+                restore()
+                flag = torch.tensor([1.0 if same else 0.0], device=self.dev)
+                self.comm.all_reduce_(flag, ops._stream(flag))
+                torch.cuda.synchronize()
+            except Exception as e:             # never let the check itself take a run down: eager is always correct
+                print(' rank %d: self-check of the captured multi-rank step failed to run (%s): steps stay eager' % (self.rank, e), flush=True)
+                restore()
+                self._graph_checked = True
+                self.use_graph, self._graphs = False, None
+                return
+            self._graph_checked = True
+            if int(round(float(flag))) != self.world:
+                print(' rank %d: the captured multi-rank step did not reproduce an eager step bit for bit (this rank: %s): steps stay eager'
+                      % (self.rank, 'same' if same else 'DIFFERENT'), flush=True)
+                self.use_graph, self._graphs = False, None
+                return
         self._graphs = (g1, None)
 
     def step(self, table=None, augs=None, lr=None, shift=None, tables2=None):

@@ -351,7 +351,7 @@ def main():
     from aphantasia_amd.clip import LOSS_SCALE
     if a.vit_path:                          # A/B runs only: the default line never passes this
         from aphantasia_amd import _ffi
-        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', ws='aph_gemm_set_ws_min_tiles')
+        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles')
         for kv in a.vit_path.split(','):
             k, v = kv.split('=')
             getattr(_ffi.lib().cdll, hooks[k])(int(v))

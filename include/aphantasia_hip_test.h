@@ -59,6 +59,9 @@ int aph_gemm_set_ws_min_tiles(int tiles);
 /* Largest batch, in token rows (cuts x tokens per cut), whose forward runs the fused block kernels (LayerNorm inside the QKV / fc1
  * launches, attention behind the QKV GEMM: csrc/vit_block.h; sequences of at most 64 tokens only); 0 = never.  Returns the previous value. */
 int aph_vit_set_fused_max_rows(int rows);
+/* Inside the fused forward: the (cut, head) LayerNorm + QKV + attention kernel 0 = never (LayerNorm + QKV on the flat-row kernel, attention
+ * as its own launch), 1 = while cuts x heads workgroups fit the chip in one round (default), 2 = always.  Returns the previous value. */
+int aph_vit_set_fused_attn(int mode);
 /* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
  * GEMMs of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */

@@ -141,6 +141,25 @@ def test_vit(emu):
     K.check_vit(emu, 'cpu')
 
 
+@pytest.mark.parametrize('fattn', [0, 2])
+def test_vit_fused_forward_blocks(emu, fattn):
+    """csrc/vit_block.h: LayerNorm inside the QKV / fc1 launches (DPP-row prologue into the resident A block), with (2) and without (0) the
+    attention behind the (cut, head) QKV GEMM; T = 5 (one ragged tile), 17 (two row blocks of the flat kernel at S = 5) and 50 tokens.
+    The same switch turns the fused BACKWARD on (a block's closing ln_1 input-gradient as the prologue of the next block's fc2 dgrad,
+    fp32 stream handed over through a second buffer; the last block's class-rows-only residual included): check_vit covers both"""
+    prev = emu.cdll.aph_vit_set_fused_max_rows(1 << 30)
+    prev_a = emu.cdll.aph_vit_set_fused_attn(fattn)
+    try:
+        K.check_vit(emu, 'cpu', check_fuse=False)
+        cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)      # T = 17
+        K.check_vit(emu, 'cpu', cfg, S=5, check_fuse=False)
+        cfg = dict(input_resolution=112, patch_size=16, width=256, layers=2, heads=4, output_dim=128)     # T = 50
+        K.check_vit(emu, 'cpu', cfg, S=2, check_fuse=False)
+    finally:
+        emu.cdll.aph_vit_set_fused_max_rows(prev)
+        emu.cdll.aph_vit_set_fused_attn(prev_a)
+
+
 def test_vit_split_precision_forward(emu):
     """aph_vit_forward_hilo / aph_patchify_f16_hilo: [hi | lo] patch rows and first-LayerNorm outputs, GEMMs over twice the K; the saved
     activations serve the unchanged backward"""

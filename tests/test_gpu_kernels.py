@@ -238,6 +238,35 @@ def test_gemm_register_staged_small_m_vs_matmul_and_reproducible():
                 assert torch.equal(ops.gemm_f16(A, Bt, tile_cfg=cfg), ref), (M, N, Kd, cfg, i)
 
 
+@pytest.mark.parametrize('fattn', [0, 2])
+def test_vit_fused_forward_blocks(fattn):
+    """csrc/vit_block.h on hardware: tiny and ViT-B/32-shaped models through the fused forward (LayerNorm inside the QKV / fc1 launches,
+    with and without the attention behind the QKV GEMM) against the fp32 oracle, and bit-identical on repetition"""
+    import torch
+    from aphantasia_amd import _ffi, ops
+    from aphantasia_amd.weights import synthetic_visual_weights
+    L = _ffi.lib()
+    prev = L.cdll.aph_vit_set_fused_max_rows(1 << 30)
+    prev_a = L.cdll.aph_vit_set_fused_attn(fattn)
+    try:
+        K.check_vit(None, DEV, check_fuse=False)
+        cfg = dict(input_resolution=112, patch_size=16, width=256, layers=2, heads=4, output_dim=128)     # T = 50
+        K.check_vit(None, DEV, cfg, S=7, check_fuse=False)
+        from aphantasia_amd.weights import visual_config
+        cfg = visual_config('ViT-B/32')
+        K.check_vit(None, DEV, cfg, S=5, check_fuse=False, fwd_tol=5e-3, bwd_tol=3e-2)
+        w = synthetic_visual_weights(cfg, 3)
+        vit = ops.VitHandle(cfg, w, max_batch=24)
+        x = torch.randn(24, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(DEV)
+        patches = ops.patchify(x, 32)
+        ref = vit.forward(patches, 24).clone()
+        for _ in range(5):
+            assert torch.equal(vit.forward(patches, 24), ref)
+    finally:
+        L.cdll.aph_vit_set_fused_max_rows(prev)
+        L.cdll.aph_vit_set_fused_attn(prev_a)
+
+
 def test_gemm_splitk_matches_and_is_deterministic():
     """split-K (tile_cfg 8 / 9): ordered last-block reduction -> same bits on every run, fp32-rounding close to the unsplit kernel"""
     import torch
