@@ -160,7 +160,7 @@ void launch_qkv_attn(aph_vit* v, const Layer& l, int S, hipStream_t st) {
   const int nv = v->D / 256;
   auto go = [&](auto tag) {
     constexpr int NV = decltype(tag)::value;
-    launch_blk_qkv_attn<NV, 8>(l.x_in, l.ln1_g, l.ln1_b, l.w_qkv, l.b_qkv, l.qkv, l.att, l.lse, S, v->T, v->heads, st);
+    launch_blk_qkv_attn<NV, 4>(l.x_in, l.ln1_g, l.ln1_b, l.w_qkv, l.b_qkv, l.qkv, l.att, l.lse, S, v->T, v->heads, st);
   };
   switch (nv) {
     case 1: go(std::integral_constant<int, 1>{}); break;
@@ -173,19 +173,19 @@ template <class Epi>
 void launch_lnbwd_gemm(aph_vit* v, const half_t* dy, const float* x, const float* g, const float* res, float* out32, int res_T, int M, const half_t* Wt,
                        int N, Epi epi, hipStream_t st) {
   switch (v->D / 256) {
-    case 1: launch_blk_lnbwd_gemm<1, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
-    case 2: launch_blk_lnbwd_gemm<2, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
-    case 3: launch_blk_lnbwd_gemm<3, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
-    default: launch_blk_lnbwd_gemm<4, 8>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    case 1: launch_blk_lnbwd_gemm<1, 4>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    case 2: launch_blk_lnbwd_gemm<2, 4>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    case 3: launch_blk_lnbwd_gemm<3, 4>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
+    default: launch_blk_lnbwd_gemm<4, 4>(dy, x, g, res, out32, res_T, M, Wt, N, epi, st); break;
   }
 }
 template <class Epi>
 void launch_ln_gemm(aph_vit* v, const float* x, int xs, int M, const float* g, const float* b, const half_t* Wt, int N, Epi epi, hipStream_t st) {
   switch (v->D / 256) {
-    case 1: launch_blk_ln_gemm<1, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
-    case 2: launch_blk_ln_gemm<2, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
-    case 3: launch_blk_ln_gemm<3, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
-    default: launch_blk_ln_gemm<4, 8>(x, xs, M, g, b, Wt, N, epi, st); break;
+    case 1: launch_blk_ln_gemm<1, 4>(x, xs, M, g, b, Wt, N, epi, st); break;
+    case 2: launch_blk_ln_gemm<2, 4>(x, xs, M, g, b, Wt, N, epi, st); break;
+    case 3: launch_blk_ln_gemm<3, 4>(x, xs, M, g, b, Wt, N, epi, st); break;
+    default: launch_blk_ln_gemm<4, 4>(x, xs, M, g, b, Wt, N, epi, st); break;
   }
 }
 

@@ -46,6 +46,16 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 #endif
 }
+// LayerNorm gain / bias into LDS (dst: 2 D floats, gain first; bias may be null): the prologues read them from there -- as loop-invariant
+// GLOBAL loads the compiler kept all 2 D / 16 quads of a lane in registers across the row batches (96 VGPRs at D = 768) and spilled
+template <int NV>
+__device__ __forceinline__ void blk_stage_affine(float* dst, const float* __restrict__ gamma, const float* __restrict__ beta) {
+  constexpr int D = 256 * NV;
+  for (int i = threadIdx.x * 4; i < D; i += 256 * 4) {
+    *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(gamma + i);
+    if (beta) *reinterpret_cast<f32x4*>(dst + D + i) = *reinterpret_cast<const f32x4*>(beta + i);
+  }
+}
 // nothing is scheduled across this point (pins the order "all loads first": the scheduler otherwise sinks them to their uses to save registers)
 __device__ __forceinline__ void blk_sched_fence() {
 #ifndef APH_EMU
@@ -57,43 +67,50 @@ __device__ __forceinline__ void blk_sched_fence() {
 // rows 16 w .. 16 w + 15, FOUR AT A TIME: a row belongs to the 16 lanes of a DPP row (lane >> 4), a lane holds the elements
 // d = 64 i + 4 (lane & 15) + 0..3 of it (16 lanes x 16 bytes = 256 contiguous bytes per row and load).  All of the wave's rows are requested
 // before the first is reduced (rows past nrows re-read the last valid one: no load sits behind a condition).  Element d of row r goes to
-// k-step d >> 5, chunk (d >> 3) & 3 of the image (rs_swz placement).
+// k-step d >> 5, chunk (d >> 3) & 3 of the image (rs_swz placement).  gamma / beta: the LDS copies (blk_stage_affine).
 template <int NV>
 __device__ __forceinline__ void blk_ln_fill(char* a_img, const float* __restrict__ x, size_t xstride, int nrows, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, int wave, int lane) {
   constexpr int D = 256 * NV, NE = D / 64;               // f32x4 pieces per lane and row
   const int c16 = lane & 15, sub = lane >> 4;
-  f32x4 v[4][NE];
+  // two batches of eight rows per wave: a batch's 2 NE loads per lane fly together (a wave addresses 256 arch VGPRs: sixteen rows at once
+  // next to the weight prefetch made the compiler park registers in AGPRs behind vmcnt(0) waits -- one serialised round trip per load,
+  // 20 us of prologue: profiles/r05_kernel_stats_s26_fused_v2.csv)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = 16 * wave + 4 * p + sub, rr = r < nrows ? r : nrows - 1;
+  for (int b0 = 0; b0 < 4; b0 += 2) {
+    f32x4 v[2][NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) v[p][i] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * xstride + i * 64 + c16 * 4);
-  }
-  blk_sched_fence();
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * wave + 4 * (b0 + p) + sub, rr = r < nrows ? r : nrows - 1;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = 16 * wave + 4 * p + sub;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
-    const float mean = row16_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NE; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float c = v[p][i][e] - mean; q += c * c; }
-    const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + kLnEps);
-    const bool live = r < nrows;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 64 + c16 * 4), b = *reinterpret_cast<const f32x4*>(beta + i * 64 + c16 * 4);
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = live ? (v[p][i][e] - mean) * rstd * g[e] + b[e] : 0.f;
-      const int ks = 2 * i + (c16 >> 3), c = (c16 >> 1) & 3;
-      *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (c16 & 1) * 8) = blk_h4(o);
+      for (int i = 0; i < NE; ++i) v[p][i] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * xstride + i * 64 + c16 * 4);
     }
+    blk_sched_fence();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * wave + 4 * (b0 + p) + sub;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
+      const float mean = row16_sum(s) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c = v[p][i][e] - mean; q += c * c; }
+      const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + kLnEps);
+      const bool live = r < nrows;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 64 + c16 * 4), b = *reinterpret_cast<const f32x4*>(beta + i * 64 + c16 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = live ? (v[p][i][e] - mean) * rstd * g[e] + b[e] : 0.f;
+        const int ks = 2 * i + (c16 >> 3), c = (c16 >> 1) & 3;
+        *reinterpret_cast<half4*>(a_img + ks * 4096 + r * 64 + ((c ^ rs_swz(r)) << 4) + (c16 & 1) * 8) = blk_h4(o);
+      }
+    }
+    blk_sched_fence();
   }
 }
 
@@ -101,7 +118,7 @@ __device__ __forceinline__ void blk_ln_fill(char* a_img, const float* __restrict
 template <int NV>
 struct BlkQKV {
   static constexpr int D = 256 * NV, NKS = 8 * NV, NT = 3;
-  static constexpr int SMEM = NKS * 4096 + 4 * 2 * NT * 1024;        // resident A block + per-wave weight images (the attention tiles alias the A block)
+  static constexpr int SMEM = NKS * 4096 + 4 * 2 * NT * 1024 + 2 * D * 4;      // resident A block + per-wave weight images + gain / bias (the attention tiles alias the A block)
 };
 
 template <int NV, int PD>
@@ -119,10 +136,14 @@ __global__ __launch_bounds__(256) void blk_qkv_attn_kernel(const float* __restri
 #pragma unroll
   for (int nt = 0; nt < 3; ++nt)      // tile nt = section (q, k, v); tile row i = lrow is the head's column 16 wave + i of that section
     woff[nt] = ((unsigned)(nt * D + h * 64 + 16 * wave + L.lrow) * (unsigned)D + L.lpc * 8) * 2u;
+  float* aff = reinterpret_cast<float*>(smem + C::NKS * 4096 + 4 * 2 * 3 * 1024);
+  blk_stage_affine<NV>(aff, gamma, beta);                            // (requested first: its wait must not cover the weight prefetch)
+  blk_sched_fence();
   ARStream<3, PD> W;
   W.template prefetch<C::NKS>(Bb, woff);                             // the first weight k-steps fly during the LayerNorm
   blk_sched_fence();
-  blk_ln_fill<NV>(smem, x + (size_t)s * T * D, D, T, gamma, beta, wave, lane);
+  __syncthreads();
+  blk_ln_fill<NV>(smem, x + (size_t)s * T * D, D, T, aff, aff + D, wave, lane);
   __syncthreads();
   f32x4 acc[4][3];
 #pragma unroll
@@ -184,11 +205,15 @@ __global__ __launch_bounds__(256) void blk_ln_gemm_kernel(const float* __restric
   unsigned woff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) woff[nt] = ((unsigned)(n0 + 4 * NT * (L.lrow >> 2) + 4 * nt + (L.lrow & 3)) * (unsigned)D + L.lpc * 8) * 2u;
+  float* aff = reinterpret_cast<float*>(smem + C::smem(D));
+  blk_stage_affine<NV>(aff, gamma, beta);
+  blk_sched_fence();
   ARStream<NT, PD> W;
   W.template prefetch<NKS>(Bb, woff);
   blk_sched_fence();
   const int nrows = M - m0 < C::BM ? M - m0 : C::BM;
-  blk_ln_fill<NV>(smem, x + (size_t)m0 * xs * D, (size_t)xs * D, nrows, gamma, beta, wave, lane);
+  __syncthreads();
+  blk_ln_fill<NV>(smem, x + (size_t)m0 * xs * D, (size_t)xs * D, nrows, aff, aff + D, wave, lane);
   __syncthreads();
   f32x4 acc[4][NT];
 #pragma unroll
@@ -210,18 +235,18 @@ __global__ __launch_bounds__(256) void blk_ln_gemm_kernel(const float* __restric
 // Prologue: g = [res +] rstd (gamma dy - mean(gamma dy) - xhat mean(gamma dy xhat)) for 64 rows (the arithmetic of ln_bwd_kernel; x = the
 // LayerNorm's input, statistics recomputed), f16(g) into the resident A block, and -- from the workgroups of column group 0 only -- g in
 // fp32 to out32 (a buffer OTHER than res: the other column groups still read res).  res_T > 0: only the rows with row % res_T == 0 have a
-// residual (see ln_bwd_kernel).  Rows in two batches of eight per wave (x, dy and res of a batch in flight together).
+// residual (see ln_bwd_kernel).  Rows in four batches of four per wave (x, dy and res of a batch in flight together: 30 registers per row).
 template <int NV>
 __device__ __forceinline__ void blk_lnbwd_fill(char* a_img, const half_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                const float* __restrict__ res, float* __restrict__ out32, int m0, int nrows, int res_T, int wave, int lane) {
   constexpr int D = 256 * NV, NE = D / 64;
   const int c16 = lane & 15, sub = lane >> 4;
 #pragma unroll
-  for (int b0 = 0; b0 < 4; b0 += 2) {
-    f32x4 xv[2][NE], rv[2][NE];
-    half4 dv[2][NE];
+  for (int b0 = 0; b0 < 4; ++b0) {
+    f32x4 xv[1][NE], rv[1][NE];
+    half4 dv[1][NE];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 1; ++p) {
       const int r = 16 * wave + 4 * (b0 + p) + sub, rr = r < nrows ? r : nrows - 1;
       const size_t row = (size_t)(m0 + rr) * D;
 #pragma unroll
@@ -233,7 +258,7 @@ __device__ __forceinline__ void blk_lnbwd_fill(char* a_img, const half_t* __rest
     }
     blk_sched_fence();
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 1; ++p) {
       const int r = 16 * wave + 4 * (b0 + p) + sub;
       float s = 0.f;
 #pragma unroll
@@ -295,11 +320,15 @@ __global__ __launch_bounds__(256) void blk_lnbwd_gemm_kernel(const half_t* __res
   unsigned woff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) woff[nt] = ((unsigned)(n0 + 4 * NT * (L.lrow >> 2) + 4 * nt + (L.lrow & 3)) * (unsigned)D + L.lpc * 8) * 2u;
+  float* aff = reinterpret_cast<float*>(smem + C::smem(D));
+  blk_stage_affine<NV>(aff, gamma, nullptr);
+  blk_sched_fence();
   ARStream<NT, PD> W;
   W.template prefetch<NKS>(Bb, woff);
   blk_sched_fence();
   const int nrows = M - m0 < C::BM ? M - m0 : C::BM;
-  blk_lnbwd_fill<NV>(smem, dy, x, gamma, res, tn == 0 ? out32 : nullptr, m0, nrows, res_T, wave, lane);
+  __syncthreads();
+  blk_lnbwd_fill<NV>(smem, dy, x, aff, res, tn == 0 ? out32 : nullptr, m0, nrows, res_T, wave, lane);
   __syncthreads();
   f32x4 acc[4][NT];
 #pragma unroll
@@ -321,7 +350,7 @@ template <int NV, int PD, class Epi>
 inline void launch_blk_lnbwd_gemm(const half_t* dy, const float* x, const float* gamma, const float* res, float* out32, int res_T, int M, const half_t* Wt,
                                   int N, Epi epi, hipStream_t st) {
   using C = GemmAR<4>;
-  const int smem = C::smem(256 * NV);
+  const int smem = C::smem(256 * NV) + 2 * 256 * NV * 4;
   APH_ALLOW_SMEM((blk_lnbwd_gemm_kernel<NV, PD, Epi>), smem);
   APH_LAUNCH((blk_lnbwd_gemm_kernel<NV, PD, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(256), smem, st, dy, x, gamma, res, out32, res_T, M,
              Wt, N, epi);
@@ -330,7 +359,7 @@ inline void launch_blk_lnbwd_gemm(const half_t* dy, const float* x, const float*
 template <int NV, int PD, class Epi>
 inline void launch_blk_ln_gemm(const float* x, int xs, int M, const float* gamma, const float* beta, const half_t* Wt, int N, Epi epi, hipStream_t st) {
   using C = GemmAR<4>;
-  const int smem = C::smem(256 * NV);
+  const int smem = C::smem(256 * NV) + 2 * 256 * NV * 4;
   APH_ALLOW_SMEM((blk_ln_gemm_kernel<NV, PD, Epi>), smem);
   APH_LAUNCH((blk_ln_gemm_kernel<NV, PD, Epi>), dim3((N / C::BN) * ((M + C::BM - 1) / C::BM)), dim3(256), smem, st, x, xs, M, gamma, beta, Wt, N, epi);
 }
