@@ -76,7 +76,7 @@ __device__ __forceinline__ void blk_ln_fill(char* a_img, const float* __restrict
   // two batches of eight rows per wave: a batch's 2 NE loads per lane fly together (a wave addresses 256 arch VGPRs: sixteen rows at once
   // next to the weight prefetch made the compiler park registers in AGPRs behind vmcnt(0) waits -- one serialised round trip per load,
   // 20 us of prologue: profiles/r05_kernel_stats_s26_fused_v2.csv)
-#pragma unroll
+#pragma unroll 1
   for (int b0 = 0; b0 < 4; b0 += 2) {
     f32x4 v[2][NE];
 #pragma unroll
@@ -241,7 +241,7 @@ __device__ __forceinline__ void blk_lnbwd_fill(char* a_img, const half_t* __rest
                                                const float* __restrict__ res, float* __restrict__ out32, int m0, int nrows, int res_T, int wave, int lane) {
   constexpr int D = 256 * NV, NE = D / 64;
   const int c16 = lane & 15, sub = lane >> 4;
-#pragma unroll
+#pragma unroll 1
   for (int b0 = 0; b0 < 4; ++b0) {
     f32x4 xv[1][NE], rv[1][NE];
     half4 dv[1][NE];

@@ -137,18 +137,27 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const half_t* __restrict__
     wave_lds_fence();
     frags(f[0], ring);
     rs_stamp(trace, 1);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) {
-        char* img = ring + ((s + 1) & 1) * C::IMG;
+    // rolled steady state + unrolled tail (see ARStream::run: straight-line code of this length misses the instruction cache in the step)
+    constexpr int U = (PD % 2) ? 2 * PD : PD;
+    constexpr int NMAIN = NS > PD + 1 ? ((NS - PD - 1) / U) * U : 0;
+    auto step = [&](int s, int u, bool more, bool req) {
+      if (more) {
+        char* img = ring + ((u + 1) & 1) * C::IMG;
         wave_lds_fence();                                     // (the fragment reads of k-step s - 1 from this image are behind every lane)
-        stage(img, R[(s + 1) % PD]);
-        if (s + 1 + PD < NS) load(s + 1 + PD, R[(s + 1) % PD]);
+        stage(img, R[(u + 1) % PD]);
+        if (req) load(s + 1 + PD, R[(u + 1) % PD]);
         wave_lds_fence();
-        frags(f[(s + 1) & 1], img);
+        frags(f[(u + 1) & 1], img);
       }
-      mma(f[s & 1]);
+      mma(f[u & 1]);
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 < NMAIN; s0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) step(s0 + u, u, true, true);
     }
+#pragma unroll
+    for (int s = NMAIN; s < NS; ++s) step(s, s % U, s + 1 < NS, s + 1 + PD < NS);
   }
   // the four partial tiles meet in LDS: [source wave][row tile][column tile][lane] as f32x4
   rs_stamp(trace, 2);
@@ -265,21 +274,33 @@ struct ARStream {
     if (PD < NKS) request(PD, 0, Bb, woff);
     wave_lds_fence();
     frags(f[0], wimg, 0);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      if (s + 1 < NKS) {
-        char* img = wimg + ((s + 1) & 1) * (NT * 1024);
+    // Steady state as a ROLLED loop of U k-steps per trip (every step of it requests a k-step: no load behind a condition, exact vmcnt
+    // bookkeeping), the last steps unrolled with compile-time conditions.  Fully unrolled, the loop was ~14 KiB of straight-line code that a
+    // wave runs through once: in the step, where three dozen kernels take turns, that is an instruction-cache miss stream per launch
+    // (18-21 us in the step against 13 us back to back: profiles/r05_gemm_rs_shapes.txt, r05_kernel_stats_s26_fused_v3.csv).
+    constexpr int U = (PD % 2) ? 2 * PD : PD;
+    constexpr int NMAIN = NKS > PD + 1 ? ((NKS - PD - 1) / U) * U : 0;
+    auto step = [&](int s, int u, bool more, bool req) {          // k-step s (register set / image parity by u = s mod U)
+      if (more) {
+        char* img = wimg + ((u + 1) & 1) * (NT * 1024);
         wave_lds_fence();
-        stage(img, (s + 1) % PD);
-        if (s + 1 + PD < NKS) request(s + 1 + PD, (s + 1) % PD, Bb, woff);
+        stage(img, (u + 1) % PD);
+        if (req) request(s + 1 + PD, (u + 1) % PD, Bb, woff);
         wave_lds_fence();
-        frags(f[(s + 1) & 1], img, s + 1);
+        frags(f[(u + 1) & 1], img, s + 1);
       }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f[s & 1].w[nt], f[s & 1].t[mt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f[u & 1].w[nt], f[u & 1].t[mt], acc[mt][nt]);
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 < NMAIN; s0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) step(s0 + u, u, true, true);
     }
+#pragma unroll
+    for (int s = NMAIN; s < NKS; ++s) step(s, s % U, s + 1 < NKS, s + 1 + PD < NKS);
   }
 };
 
