@@ -74,10 +74,7 @@ _PROTOTYPES = {
     'aph_gemm_set_ws_min_tiles': (c_int, [c_int]),
     'aph_gemm_set_ws_pgroup': (c_int, [c_int]),
     'aph_gemm_set_rs': (c_int, [c_int]),
-    'aph_vit_set_fused_max_rows': (c_int, [c_int]),
-    'aph_vit_set_fused_attn': (c_int, [c_int]),
     'aph_mfma_rate': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'aph_gemm_pack_frag': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'aph_gemm_rs_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_gemm_ws_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_gemm_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -97,6 +94,13 @@ _PROTOTYPES = {
 
 EXPORTS = tuple(_PROTOTYPES)
 
+# hooks of a -DAPH_EXPERIMENTS build (include/aphantasia_hip_experiments.h): bound when the loaded library has them
+_EXPERIMENT_PROTOTYPES = {
+    'aph_vit_set_fused_max_rows': (c_int, [c_int]),
+    'aph_vit_set_fused_attn': (c_int, [c_int]),
+    'aph_gemm_pack_frag': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+
 
 class Library:
     """A loaded C-ABI library with checked calls: `lib.call('aph_x', ...)` raises RuntimeError with
@@ -114,6 +118,12 @@ class Library:
             fn = getattr(self.cdll, name)     # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        self.experiments = all(hasattr(self.cdll, n) for n in _EXPERIMENT_PROTOTYPES)
+        if self.experiments:
+            for name, (res, args) in _EXPERIMENT_PROTOTYPES.items():
+                fn = getattr(self.cdll, name)
+                fn.restype = res
+                fn.argtypes = args
 
     def last_error(self):
         return (self.cdll.aph_last_error() or b'').decode(errors='replace')

@@ -16,7 +16,9 @@
 #include "vit_gemm_rs.h"
 #include "vit_ops.h"
 #include "vit_attn.h"
+#ifdef APH_EXPERIMENTS
 #include "vit_block.h"
+#endif
 
 using namespace aph;
 
@@ -143,6 +145,7 @@ void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int 
   vtimed(v, 2.0 * M * N * K, st, [&] { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); });
 }
 
+#ifdef APH_EXPERIMENTS
 // Fused block kernels (vit_block.h) for short sequences: used while the batch has at most this many token rows (0 = never).  Above it the
 // one-launch-per-operator path with the wave-specialised GEMM is the faster one (measured crossover: DESIGN.md section 4).
 #ifndef APH_VIT_FUSED_MAX_ROWS_DEFAULT
@@ -188,6 +191,10 @@ void launch_ln_gemm(aph_vit* v, const float* x, int xs, int M, const float* g, c
     default: launch_blk_ln_gemm<4, 4>(x, xs, M, g, b, Wt, N, epi, st); break;
   }
 }
+
+#else
+inline bool vit_fused(const aph_vit*, int) { return false; }
+#endif
 
 // g2 / b2 / out2: the next LayerNorm of the same rows fused behind this one (ln_fwd_kernel)
 template <bool OUT_F16, bool CLS>
@@ -397,12 +404,15 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
   for (int li = 0; li < v->L; ++li) {
     Layer& l = v->layers[li];
     float* x_next = li + 1 < v->L ? v->layers[li + 1].x_in : v->x_last;
+#ifdef APH_EXPERIMENTS
     if (blk && vit_fused_attn(v, S)) {
       vtimed(v, 2.0 * M * 3 * D * D + 4.0 * S * v->heads * T * T * 64, st, [&] { launch_qkv_attn(v, l, S, st); });
     } else if (blk) {
       vtimed(v, 2.0 * M * 3 * D * D, st, [&] { launch_ln_gemm(v, l.x_in, 1, M, l.ln1_g, l.ln1_b, l.w_qkv, 3 * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st); });
       launch_attn_fwd(attn_args(v, l, S), st);
-    } else {
+    } else
+#endif
+    {
       if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
       vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
       launch_attn_fwd(attn_args(v, l, S), st);
@@ -412,9 +422,12 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
     const bool cls_only = li + 1 == v->L;
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
     vgemm(v, l.att, rs * D, l.w_o, D, Mr, D, D, EpiResidual{l.x_mid, l.x_in, rs * D, l.b_o}, st);
+#ifdef APH_EXPERIMENTS
     if (blk) {
       vtimed(v, 2.0 * Mr * 4 * D * D, st, [&] { launch_ln_gemm(v, l.x_mid, rs, Mr, l.ln2_g, l.ln2_b, l.w_fc1, 4 * D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st); });
-    } else {
+    } else
+#endif
+    {
       launch_ln_fwd<true, false>(nv, l.x_mid, l.ln2_g, l.ln2_b, v->h, Mr, T, nullptr, nullptr, nullptr, st, rs);
       vgemm(v, v->h, D, l.w_fc1, D, Mr, 4 * D, D, EpiGelu{l.u, v->gact, 4 * D, l.b_fc1}, st);
     }
@@ -450,7 +463,7 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   if (!fuse) zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
-  // fused backward (vit_block.h): a block's closing ln_1 backward is not launched; it runs as the prologue of the NEXT (lower) block's fc2
+  // fused backward (vit_block.h, -DAPH_EXPERIMENTS builds): a block's closing ln_1 backward is not launched; it runs as the prologue of the NEXT (lower) block's fc2
   // dgrad -- `pending` carries it over: dy = v->dh, LayerNorm input = the upper block's x_in, residual = v->dx (only the rows % res_T == 0)
   const bool blk = vit_fused(v, S);
   bool pending = false;
@@ -461,6 +474,7 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
     const int Mr = cls_only ? S : M, rs = cls_only ? T : 1;
     if (cls_only) zero_fill_async(v->datt, sizeof(half_t) * (size_t)M * D, st);   // no gradient into the other rows' attention output
     const float* res2 = v->dx;                      // residual of this block's ln_2 backward
+#ifdef APH_EXPERIMENTS
     if (pending) {
       const Layer& up = v->layers[li + 1];
       vtimed(v, 2.0 * M * 4 * D * D, st, [&] {
@@ -468,7 +482,9 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
       });
       res2 = v->dx2;
       pending = false;
-    } else {
+    } else
+#endif
+    {
       vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
     }
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
@@ -535,6 +551,7 @@ int aph_vit_set_fuse_ln(int on) {
   return prev;
 }
 
+#ifdef APH_EXPERIMENTS
 // largest batch (token rows S * T) that runs the fused block kernels of vit_block.h (0 = never).  Returns the previous value.
 int aph_vit_set_fused_max_rows(int rows) {
   const int prev = g_fused_max_rows;
@@ -549,6 +566,8 @@ int aph_vit_set_fused_attn(int mode) {
   g_fused_attn = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return prev;
 }
+
+#endif  // APH_EXPERIMENTS
 
 int aph_gemm_set_mfma32(int on) {
   const int prev = gemm_mfma32();
@@ -639,9 +658,18 @@ int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
 // issued, fill barrier passed, main loop done, end).  d_trace: (workgroups x 8) uint64 or NULL.
 int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, int kind, unsigned long long* d_trace, void* stream_) {
   APH_TRY
-  if (!d_A || !d_Bt || !d_out || M < 1 || !gemm8_addressable(M, K, N, K) || (kind == 0 ? !gemm_sk_fits(N, K) : !gemm_ar_fits(N, K)))
-    return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: bad shape");
+#ifdef APH_EXPERIMENTS
+  const bool fits = kind == 0 ? gemm_sk_fits(N, K) : gemm_ar_fits(N, K);
+#else
+  const bool fits = gemm_sk_fits(N, K);
+#endif
+  if (!d_A || !d_Bt || !d_out || M < 1 || !gemm8_addressable(M, K, N, K) || !fits) return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: bad shape");
   const EpiF16 epi{(half_t*)d_out, N, nullptr};
+#ifndef APH_EXPERIMENTS
+  if (kind != 0) return aph_fail(APH_ERR_UNSUPPORTED, "aph_gemm_rs_probe: kinds 1 / 2 (A-resident kernels) exist in -DAPH_EXPERIMENTS builds only");
+  launch_gemm_sk<4>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
+  return aph_check_launch("aph_gemm_rs_probe");
+#else
   if (kind == 2) {        // d_Bt = the fragment-major image written by aph_gemm_pack_frag (experiment: K = 768 only)
     if (K != 768) return aph_fail(APH_ERR_ARG, "aph_gemm_rs_probe: kind 2 is instantiated for K = 768");
     using C = GemmAR<4>;
@@ -653,9 +681,11 @@ int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
   if (kind == 0) launch_gemm_sk<4>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
   else launch_gemm_ar<4, 8>((const half_t*)d_A, K, (const half_t*)d_Bt, K, M, N, K, epi, (hipStream_t)stream_, d_trace);
   return aph_check_launch("aph_gemm_rs_probe");
+#endif
   APH_CATCH
 }
 
+#ifdef APH_EXPERIMENTS
 // Bt [N, K] f16 -> fragment-major image for the A-resident kernel's 256-column groups (experiment hook)
 int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream_) {
   APH_TRY
@@ -665,6 +695,8 @@ int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream
   return aph_check_launch("aph_gemm_pack_frag");
   APH_CATCH
 }
+
+#endif
 
 // the attention kernels alone (unit tests, micro-benchmarks): mode 0 = forward (qkv -> att, lse), 1 = backward
 // ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16, att / datt [S*T, heads*64] f16, lse [S*heads*T] f32,
@@ -703,7 +735,7 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   tile_cfg &= 0xff;
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
       !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || (tile_cfg >= 14 && tile_cfg <= 17) || tile_cfg == 22 || tile_cfg == 24) ||
-      (tile_cfg >= 14 && tile_cfg <= 17 && !gemm8_addressable(M, lda, N, ldb)) || (tile_cfg >= 16 && tile_cfg <= 17 && !gemm_ar_fits(N, K)) || (tile_cfg >= 14 && tile_cfg <= 15 && !gemm_sk_fits(N, K)) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
+      (tile_cfg >= 14 && tile_cfg <= 17 && !gemm8_addressable(M, lda, N, ldb)) || (tile_cfg >= 14 && tile_cfg <= 15 && !gemm_sk_fits(N, K)) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;
@@ -743,8 +775,12 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 12) launch_gemm_cfg<GemmFat>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 14) launch_gemm_sk<4>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 15) launch_gemm_sk<3>(A, lda, B, ldb, M, N, K, epi, st);
+#ifdef APH_EXPERIMENTS
   else if (tile_cfg == 16) launch_gemm_ar<4, 8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 17) launch_gemm_ar<4, 4>(A, lda, B, ldb, M, N, K, epi, st);
+#else
+  else if (tile_cfg == 16 || tile_cfg == 17) return aph_fail(APH_ERR_UNSUPPORTED, "aph_gemm_f16_ld: tile_cfg 16 / 17 (A-resident kernel) exist in -DAPH_EXPERIMENTS builds only");
+#endif
   else launch_gemm(A, lda, B, ldb, M, N, K, epi, st);
   return aph_check_launch("aph_gemm_f16_ld");
   APH_CATCH

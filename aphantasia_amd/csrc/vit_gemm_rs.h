@@ -206,6 +206,8 @@ inline void launch_gemm_sk(const half_t* A, int lda, const half_t* Bt, int ldb, 
   }
 }
 
+#ifdef APH_EXPERIMENTS       // measured slower than the ring kernels inside the step at every shard size (profiles/r05_gemm_rs_shapes.txt,
+                             // r05_fused_v4_steps.txt): compiled for A/B builds and the CPU interpreter only, not into the product library
 // ---- A-resident kernel ----------------------------------------------------------------------------------------------------------------
 // shared pieces (also used by vit_block.h): the resident A block is nks k-step images of [64 rows][64 bytes]; behind it every wave has two
 // private images of [16 NT weight rows][64 bytes].
@@ -476,8 +478,10 @@ inline void launch_gemm_ar(const half_t* A, int lda, const half_t* Bt, int ldb, 
   }
 }
 
-// which kernel: the A-resident one for wide outputs over K = width, split-K for the narrow outputs over a long K; false: neither is
-// instantiated for this shape (the caller falls back to the ring kernels of vit_gemm.h)
+#endif  // APH_EXPERIMENTS
+
+// the split-K kernel if it is instantiated for this shape (false: the caller falls back to the ring kernels of vit_gemm.h); `wide`
+// (-DAPH_EXPERIMENTS builds): the A-resident kernel for wide outputs over K = width
 template <class Epi>
 inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, bool wide) {
 #ifdef APH_EXPERIMENTS      // (the A-resident kernel behind every wide ViT GEMM: measured slower than the ring kernels in the step; A/B builds only)

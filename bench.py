@@ -246,7 +246,7 @@ def lib_sha():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-GEMM_SOURCES = ('aph_device.h', 'aph_host.h', 'vit_gemm.h', 'vit_gemm_ws.h', 'vit_ops.h', 'vit_attn.h', 'vit.hip')   # the whole ViT translation unit: GEMM kernels, launch heuristic, launch sites / epilogue choice
+GEMM_SOURCES = ('aph_device.h', 'aph_host.h', 'vit_gemm.h', 'vit_gemm_ws.h', 'vit_gemm_rs.h', 'vit_ops.h', 'vit_attn.h', 'vit.hip')   # the whole ViT translation unit: GEMM kernels, launch heuristic, launch sites / epilogue choice
 
 
 def gemm_src_sha():
@@ -354,6 +354,8 @@ def main():
         hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles')
         for kv in a.vit_path.split(','):
             k, v = kv.split('=')
+            if not hasattr(_ffi.lib().cdll, hooks[k]):
+                raise SystemExit('--vit-path %s: %s exists in -DAPH_EXPERIMENTS builds only (python -m aphantasia_amd._build --experiments)' % (kv, hooks[k]))
             getattr(_ffi.lib().cdll, hooks[k])(int(v))
     # the step's collective: RCCL called directly through the C ABI (aph_allreduce_f32); torch.distributed only carried the
     # 128-byte unique id and does the barriers / the MAX over ranks of the timing contract.  APH_COMM=torch: all-reduce through

@@ -32,7 +32,7 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *            fragments; 4 / 3 k-steps of 32 in flight), no barrier in the main loop, ordered 4-way sum at the end (vit_gemm_rs.h: the small-M
  *            default for narrow outputs)
  *   16 / 17  64x256 A-resident: the 64 x K block of A stays in LDS, every wave streams the weight rows of its 64 columns (8 / 4 k-steps in
- *            flight); needs N % 256 == 0 and K <= 1024 (the small-M default for wide outputs)
+ *            flight); needs N % 256 == 0 and K = 256 ... 1024.  -DAPH_EXPERIMENTS builds only (measured slower than 1 / 10 in the step)
  *   22 / 24  128x128 split-K x2 / x4
  * | 0x100 (with 2, 4 or 5 only): measurement variant whose epilogue keeps the accumulators live but never stores (upper bound of
  *   what overlapping the store phase could gain: tools/exp/gemm_nostore.py).
@@ -45,7 +45,8 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
  * runs: every switch here is an explicit call.) */
 int aph_crop_adjoint_set_gather(int on);
 
-/* MFMA shape of the GEMM main loops launched from now on (process-wide): 0 = v_mfma_f32_16x16x32_f16 (default: measured
+/* MFMA shape of the main loops of the GEMM TEST ENTRIES (aph_gemm_f16, aph_gemm_f16_ld; the ViT's own GEMMs are compiled for the default
+ * only) launched from now on: 0 = v_mfma_f32_16x16x32_f16 (default: measured
  * faster on MI355X with real operands -- the chip is power-limited there and the 32x32x16 form sustains less),
  * 1 = v_mfma_f32_32x32x16_f16.  Returns the previous setting.  For within-process A/B measurements and the unit tests. */
 int aph_gemm_set_mfma32(int on);
@@ -56,12 +57,6 @@ int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* Largest batch, in token rows (cuts x tokens per cut), whose forward runs the fused block kernels (LayerNorm inside the QKV / fc1
- * launches, attention behind the QKV GEMM: csrc/vit_block.h; sequences of at most 64 tokens only); 0 = never.  Returns the previous value. */
-int aph_vit_set_fused_max_rows(int rows);
-/* Inside the fused forward: the (cut, head) LayerNorm + QKV + attention kernel 0 = never (LayerNorm + QKV on the flat-row kernel, attention
- * as its own launch), 1 = while cuts x heads workgroups fit the chip in one round (default), 2 = always.  Returns the previous value. */
-int aph_vit_set_fused_attn(int mode);
 /* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
  * GEMMs of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
@@ -81,8 +76,8 @@ int aph_gemm_ws_probe(const void* d_A, const void* d_Bt, int M, int N, int K, vo
                       unsigned long long* d_trace, void* stream);
 
 /* The register-staged small-M GEMMs (tile_cfg 14 / 16) with an f16 output and per-phase stamps of the chip-wide 100 MHz clock
- * (tools/exp/gemm_rs_trace.py): kind 0 = split-K, 1 = A-resident; d_trace: (workgroups x 8) uint64 or NULL. */
-int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream);      /* experiment: fragment-major weights (probe kind 2) */
+ * (tools/exp/gemm_rs_trace.py): kind 0 = split-K (1 = A-resident, 2 = A-resident from fragment-major weights: -DAPH_EXPERIMENTS builds);
+ * d_trace: (workgroups x 8) uint64 or NULL. */
 int aph_gemm_rs_probe(const void* d_A, const void* d_Bt, int M, int N, int K, void* d_out, int kind, unsigned long long* d_trace, void* stream);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ def build():
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src + '.emu.o')
-        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-DAPH_EMU', '-Wno-unused-value', '-I', HERE, '-I', CSRC,
+        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-DAPH_EMU', '-DAPH_EXPERIMENTS', '-Wno-unused-value', '-I', HERE, '-I', CSRC,
                '-I', os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, src), '-o', obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
