@@ -140,9 +140,11 @@ void vtimed(aph_vit* v, double flops, hipStream_t st, F&& launch) {
   v->prof_used += 2;
   v->prof_flops += flops;
 }
+// kdiv: the split-precision forward runs a GEMM over K = 2 x the algorithmic K (hi | lo operand against the weights repeated along K): the
+// profile counts the ALGORITHMIC FLOPs (roofline.achieved is algorithmic work over measured time)
 template <class Epi>
-void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st) {
-  vtimed(v, 2.0 * M * N * K, st, [&] { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); });
+void vgemm(aph_vit* v, const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, int kdiv = 1) {
+  vtimed(v, 2.0 * M * N * K / kdiv, st, [&] { launch_gemm(A, lda, Bt, ldb, M, N, K, epi, st, &v->sk); });
 }
 
 #ifdef APH_EXPERIMENTS
@@ -396,7 +398,7 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   const int kx = hilo ? 2 : 1;
-  vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st);
+  vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st, kx);
   const bool fuse = g_fuse_ln != 0;
   const bool blk = !hilo && vit_fused(v, S);          // fused block kernels: LayerNorm inside the QKV / fc1 launches, attention behind the QKV GEMM
   launch_ln_fwd<false, true>(nv, v->x0, v->ln_pre_g, v->ln_pre_b, v->layers[0].x_in, M, T, v->cls, v->pos, v->x0, st, 1,
@@ -414,7 +416,7 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
 #endif
     {
       if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
-      vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+      vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st, kx);
       launch_attn_fwd(attn_args(v, l, S), st);
     }
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after
