@@ -54,6 +54,9 @@ struct GemmCfg {
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
+using GemmSmall8 = GemmCfg<4, 2, 1, 2, 4>;   //  64 x  64 on EIGHT waves (16 x 32 each): twice the waves issuing DMA per workgroup -- a cold stream fills a CU at
+                                             //  ~57 GB/s from four waves and ~77 GB/s from eight (profiles/r05_load_rate_cold_vs_warm.txt), and with <= 256 tiles
+                                             //  there is one workgroup per CU
 using GemmFat = GemmCfg<2, 2, 8, 4, 3>;      // 256 x 128, 256 threads: FOUR waves of 128x64 (one per SIMD): half the LDS fragment bytes per flop of GemmBig (experiment)
 using GemmPair = GemmCfg<2, 2, 4, 4, 2>;     // 128 x 128, 256 threads (64x64 per wave), 64 KiB: TWO workgroups per CU, one in its epilogue while the other computes (experiment)
 
@@ -780,15 +783,26 @@ inline int& gemm_ws_min_tiles() {
   return v;
 }
 
-// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows (the class-row
-// GEMMs of the last block, a one-cut batch): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce launch,
-// 5.3 against 6.0 us at N = 768 ... 3072 over K = 768 and 12.5 against 16.7 us over K = 3072 at M = 50 (profiles/r05_gemm_rs_shapes.txt);
+// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows over K <= 1024
+// (the K = width class-row GEMMs of the last block, a one-cut batch): one launch with an ordered in-kernel reduction instead of a split-K
+// launch plus its reduce launch, 7.2-8.0 against 10.9-11.3 us in the 24-cut step.  Over K = 3072 the two-pass split-K stays: its 48
+// workgroups pull the cold weight matrix through four times as many CUs (11.3 against 20 us, profiles/r05_kernel_stats_s26_fused_v4.csv);
 // 2 = every shape below the wave-specialised kernel's threshold (measured SLOWER than the ring kernels from M ~ 1200 up: same file; kept for
 // A/B runs); 0 = never.  aph_gemm_set_rs().
 template <class Epi>
 inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, bool wide);   // vit_gemm_rs.h
 inline int& gemm_rs_mode() {
   static int v = 1;
+  return v;
+}
+
+// 64 x 64 tiles on eight waves instead of four while there is at most one workgroup per CU (aph_gemm_set_small8())
+inline int& gemm_small8() {
+  static int v = 1;
+  return v;
+}
+inline int& gemm_small8_max_tiles() {
+  static int v = 256;
   return v;
 }
 
@@ -800,7 +814,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || M <= 128) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
+  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (M <= 128 && K <= 1024)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
       launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
     return;
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
@@ -808,7 +822,9 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {
     const int splits = choose_splits(M, N, K, sp);
+    const int small_tiles = (N / GemmSmall::BN) * ((M + GemmSmall::BM - 1) / GemmSmall::BM);
     if (splits > 1) launch_gemm_splitk<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, splits, *sp, st);
+    else if (gemm_small8() && small_tiles <= gemm_small8_max_tiles()) launch_gemm_cfg<GemmSmall8>(A, lda, Bt, ldb, M, N, K, epi, st);
     else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
   }
 }
