@@ -586,14 +586,6 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
 
 // small-M GEMMs (below the wave-specialised kernel's threshold) on the register-staged kernels of vit_gemm_rs.h (1, default) or on the shared-ring
 // tile configurations of vit_gemm.h (0).  Returns the previous value.
-// 64 x 64 tiles on eight waves while they number at most `max_tiles` (one workgroup per CU): on (1, default) / off (0); max_tiles <= 0 keeps
-// the current limit.  Returns the previous on / off value.
-int aph_gemm_set_small8(int on, int max_tiles) {
-  const int prev = gemm_small8();
-  gemm_small8() = on ? 1 : 0;
-  if (max_tiles > 0) gemm_small8_max_tiles() = max_tiles;
-  return prev;
-}
 int aph_gemm_set_rs(int mode) {
   const int prev = gemm_rs_mode();
   gemm_rs_mode() = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
@@ -737,14 +729,14 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 // same with explicit leading dimensions (row pitches in elements) and tile configuration
 // (0 = automatic, 1 = 64x64, 2 = 256x128, 4 = 256x256 phased [needs N % 256 == 0], 5 = 256x128 wave-specialised persistent, 8 / 9 = 64x64 split-K x2 / x4,
 // 10 = 128x128 4-stage, 11 = 128x128 4 waves 2-stage (two workgroups per CU), 12 = 256x128 on 4 waves,
-// 13 = 64x64 on eight waves, 14 / 15 = 64x64 register-staged split-K (4 / 3 k-steps in flight per wave), 16 / 17 = 64x256 A-resident (8 / 4 k-steps in flight; N % 256 == 0, K <= 1024),
+// 14 / 15 = 64x64 register-staged split-K (4 / 3 k-steps in flight per wave), 16 / 17 = 64x256 A-resident (8 / 4 k-steps in flight; N % 256 == 0, K <= 1024),
 // 22 / 24 = 128x128 split-K x2 / x4) -- unit tests and tuning sweeps
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   const bool nostore = (tile_cfg & 0x100) != 0;
   tile_cfg &= 0xff;
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
-      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || (tile_cfg >= 13 && tile_cfg <= 17) || tile_cfg == 22 || tile_cfg == 24) ||
+      !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || (tile_cfg >= 14 && tile_cfg <= 17) || tile_cfg == 22 || tile_cfg == 24) ||
       (tile_cfg >= 14 && tile_cfg <= 17 && !gemm8_addressable(M, lda, N, ldb)) || (tile_cfg >= 14 && tile_cfg <= 15 && !gemm_sk_fits(N, K)) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
@@ -783,7 +775,6 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
   else if (tile_cfg == 10) launch_gemm_cfg<GemmMidDeep8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 11) launch_gemm_cfg<GemmPair>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 12) launch_gemm_cfg<GemmFat>(A, lda, B, ldb, M, N, K, epi, st);
-  else if (tile_cfg == 13) launch_gemm_cfg<GemmSmall8>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 14) launch_gemm_sk<4>(A, lda, B, ldb, M, N, K, epi, st);
   else if (tile_cfg == 15) launch_gemm_sk<3>(A, lda, B, ldb, M, N, K, epi, st);
 #ifdef APH_EXPERIMENTS

@@ -54,9 +54,9 @@ struct GemmCfg {
 using GemmBig = GemmCfg<4, 2, 4, 4, 3>;      // 256 x 128, 512 threads, 144 KiB:  85 flop per L2 byte
 using GemmMidDeep8 = GemmCfg<4, 2, 2, 4, 4>; // 128 x 128, 512 threads (32x64 per wave), 128 KiB: 3 k-tiles in flight
 using GemmSmall = GemmCfg<2, 2, 2, 2, 4>;    //  64 x  64, 256 threads,  64 KiB
-using GemmSmall8 = GemmCfg<4, 2, 1, 2, 4>;   //  64 x  64 on EIGHT waves (16 x 32 each): twice the waves issuing DMA per workgroup -- a cold stream fills a CU at
-                                             //  ~57 GB/s from four waves and ~77 GB/s from eight (profiles/r05_load_rate_cold_vs_warm.txt), and with <= 256 tiles
-                                             //  there is one workgroup per CU
+// (Round 5, measured and rejected: the same 64 x 64 tile on EIGHT waves of 16 x 32 -- GemmCfg<4, 2, 1, 2, 4> -- on the reading that a cold stream
+// fills a CU faster from more waves: equal to the four-wave configuration on every shape at M = 300 ... 4750 and in the step at 5 ... 95 cuts,
+// profiles/r05_gemm_small8_{shapes,steps}.txt: the ring's DMA count per workgroup is what it is, whoever issues it.)
 using GemmFat = GemmCfg<2, 2, 8, 4, 3>;      // 256 x 128, 256 threads: FOUR waves of 128x64 (one per SIMD): half the LDS fragment bytes per flop of GemmBig (experiment)
 using GemmPair = GemmCfg<2, 2, 4, 4, 2>;     // 128 x 128, 256 threads (64x64 per wave), 64 KiB: TWO workgroups per CU, one in its epilogue while the other computes (experiment)
 
@@ -796,16 +796,6 @@ inline int& gemm_rs_mode() {
   return v;
 }
 
-// 64 x 64 tiles on eight waves instead of four while there is at most one workgroup per CU (aph_gemm_set_small8())
-inline int& gemm_small8() {
-  static int v = 1;
-  return v;
-}
-inline int& gemm_small8_max_tiles() {
-  static int v = 256;
-  return v;
-}
-
 template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                         const SplitKSpace* sp = nullptr) {
@@ -822,9 +812,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
   else if (mid_tiles >= 160) launch_gemm_cfg<GemmMidDeep8>(A, lda, Bt, ldb, M, N, K, epi, st);
   else {
     const int splits = choose_splits(M, N, K, sp);
-    const int small_tiles = (N / GemmSmall::BN) * ((M + GemmSmall::BM - 1) / GemmSmall::BM);
     if (splits > 1) launch_gemm_splitk<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, splits, *sp, st);
-    else if (gemm_small8() && small_tiles <= gemm_small8_max_tiles()) launch_gemm_cfg<GemmSmall8>(A, lda, Bt, ldb, M, N, K, epi, st);
     else launch_gemm_cfg<GemmSmall>(A, lda, Bt, ldb, M, N, K, epi, st);
   }
 }

@@ -352,14 +352,11 @@ def main():
     from aphantasia_amd.clip import LOSS_SCALE
     if a.vit_path:                          # A/B runs only: the default line never passes this
         from aphantasia_amd import _ffi
-        hooks = dict(small8='aph_gemm_set_small8', rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles')
+        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles')
         for kv in a.vit_path.split(','):
             k, v = kv.split('=')
             if not hasattr(_ffi.lib().cdll, hooks[k]):
                 raise SystemExit('--vit-path %s: %s exists in -DAPH_EXPERIMENTS builds only (python -m aphantasia_amd._build --experiments)' % (kv, hooks[k]))
-            if k == 'small8':
-                _ffi.lib().cdll.aph_gemm_set_small8(1 if int(v) > 0 else 0, int(v))
-                continue
             getattr(_ffi.lib().cdll, hooks[k])(int(v))
     # the step's collective: RCCL called directly through the C ABI (aph_allreduce_f32); torch.distributed only carried the
     # 128-byte unique id and does the barriers / the MAX over ranks of the timing contract.  APH_COMM=torch: all-reduce through

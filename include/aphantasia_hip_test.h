@@ -28,7 +28,6 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
  *    8 / 9   64x64 split-K x2 / x4                10  128x128, 8 waves, 4-stage ring
  *   11  128x128, 4 waves, 2-stage ring, two workgroups per CU (measured slower than 2 on every ViT shape: profiles/r02_gemm_shapes.txt)
  *   12  256x128 on four waves of 128x64, one per SIMD (measured slower than 2: same file)
- *   13  64x64 on EIGHT waves (16x32 each), 4-stage ring: the default for shapes of at most 256 such tiles (one workgroup per CU)
  *   14 / 15  64x64 register-staged split-K: each of the four waves streams its own k-tiles (global_load_dwordx4 -> private LDS image ->
  *            fragments; 4 / 3 k-steps of 32 in flight), no barrier in the main loop, ordered 4-way sum at the end (vit_gemm_rs.h: the small-M
  *            default for narrow outputs)
@@ -58,9 +57,6 @@ int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* 64x64 tiles on eight waves (tile_cfg 13) instead of four (tile_cfg 1) while a GEMM has at most max_tiles of them (default 256: one
- * workgroup per CU); on = 1 (default) / 0; max_tiles <= 0 keeps the limit.  Returns the previous on / off value. */
-int aph_gemm_set_small8(int on, int max_tiles);
 /* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
  * GEMMs over K <= 1024 of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */

@@ -105,7 +105,6 @@ def test_gemm(emu):
     K.check_gemm(emu, 'cpu', [(150, 128, 512), (64, 128, 256)], tile_cfg=9)   # split-K x4, two-pass ordered reduction
     K.check_gemm(emu, 'cpu', [(70, 128, 192)], tile_cfg=8)
     K.check_gemm(emu, 'cpu', [(200, 256, 320)], tile_cfg=10)   # 128x128, 8 waves, 4-stage ring
-    K.check_gemm(emu, 'cpu', [(200, 256, 320), (70, 128, 64)], tile_cfg=13, variants=(0,))   # 64x64 on eight waves (one 16-row MFMA tile per wave)
     K.check_gemm(emu, 'cpu', [(70, 128, 64)], tile_cfg=2)     # single k-tile, single partial tile
     # wave-specialised persistent kernel (vit_gemm_ws.h): producer / consumer waves, permuted Bt rows, register epilogue;
     # single unit, ragged single tile, 9 / 10 tiles on 3 workgroups with odd and even k-tile counts

@@ -168,7 +168,6 @@ def test_gemm_every_tile_config():
     for cfg in (1, 2, 10):
         K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64), (1200, 3072, 768)], tile_cfg=cfg)
     K.check_gemm(None, DEV, [(9500, 768, 768), (333, 256, 64)], tile_cfg=11, variants=(0,))       # two workgroups per CU (2-stage ring)
-    K.check_gemm(None, DEV, [(1200, 768, 3072), (1200, 768, 768), (333, 256, 64), (50, 768, 2304)], tile_cfg=13, variants=(0,))   # 64x64 on eight waves
 
 
 def test_gemm_wave_specialised_vs_matmul_and_reproducible():
