@@ -74,6 +74,7 @@ _PROTOTYPES = {
     'aph_gemm_set_ws_min_tiles': (c_int, [c_int]),
     'aph_gemm_set_ws_pgroup': (c_int, [c_int]),
     'aph_gemm_set_rs': (c_int, [c_int]),
+    'aph_attn_set_bwd_one': (c_int, [c_int]),
     'aph_mfma_rate': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_rs_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_gemm_ws_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

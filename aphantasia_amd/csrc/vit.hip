@@ -239,8 +239,17 @@ void launch_attn_fwd_g(const AttnArgs& a, hipStream_t st) {
   APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem);
   APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem, st, a.qkv, a.att, a.lse, a.T, a.heads);
 }
+// blocked backward (64 < T <= 256): 1 = the one-kernel form (P and dS formed once: attn_bwd_one_g_kernel), 0 = the dQ + dK/dV kernel pair
+int g_attn_bwd_one = 1;
 template <int NB>
 void launch_attn_bwd_g(const AttnArgs& a, hipStream_t st) {
+  if (g_attn_bwd_one) {
+    constexpr size_t smem = (size_t)(4 + 2 * NB) * 8192 + 2 * 64 * sizeof(float);
+    APH_ALLOW_SMEM((attn_bwd_one_g_kernel<NB>), smem);
+    APH_LAUNCH((attn_bwd_one_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse, a.dqkv,
+               a.T, a.heads);
+    return;
+  }
   constexpr size_t smem_q = (size_t)3 * NB * 8192, smem_kv = (size_t)4 * NB * 8192 + 2 * NB * 64 * sizeof(float);
   APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q);
   APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv);
@@ -586,6 +595,12 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
 
 // small-M GEMMs (below the wave-specialised kernel's threshold) on the register-staged kernels of vit_gemm_rs.h (1, default) or on the shared-ring
 // tile configurations of vit_gemm.h (0).  Returns the previous value.
+// blocked attention backward (64 < tokens <= 256): 1 = one kernel (default), 0 = the dQ + dK/dV pair.  Returns the previous value.
+int aph_attn_set_bwd_one(int on) {
+  const int prev = g_attn_bwd_one;
+  g_attn_bwd_one = on ? 1 : 0;
+  return prev;
+}
 int aph_gemm_set_rs(int mode) {
   const int prev = gemm_rs_mode();
   gemm_rs_mode() = mode < 0 ? 0 : (mode > 2 ? 2 : mode);

@@ -579,4 +579,155 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// [r5] The blocked backward as ONE kernel: P = exp(S / 8 - lse) and dS are formed ONCE per (query, key).
+// The two kernels above each recompute them because the two contractions want them in transposed register layouts: dK / dV contract over
+// QUERIES (the probabilities must be a B fragment with lane = key), dQ contracts over KEYS (lane = query) -- and at T = 197 the softmax
+// arithmetic on a lane's scores, not the matrix pipe, is what these kernels spend their time on (note above).  Here the key-stationary form
+// is kept (wave w owns the key tiles w, w + 8: K / V fragments and the dK / dV accumulators stay in registers for the whole kernel) and dS
+// takes the other layout THROUGH LDS: for one 64-query block at a time every wave writes its dS entries, f16, into a [64 queries][T key slots]
+// image (the slot order of the K^T image), and after a barrier the eight waves form the block's dQ^T = K^T dS^T tiles from that image and the
+// resident K^T -- 2 bytes written and read per score instead of a second exponential, two more MFMAs and a dozen VALU slots.
+// The row term D_i = dO_i . O_i is formed while the block's Q / dO rows are staged (threads that are not staging).
+// LDS: Q, dO row-major + transposed for ONE 64-query block (32 KiB), K^T (8 NB KiB), dS^T (8 NB KiB), lse / D: 96.5 KiB at NB = 4.
+// Two barriers per query block.  Keys / queries past T: as above (zero operand rows, finite p and dS); the dS^T image starts zeroed, so the
+// slots of key tiles nobody computes contribute nothing.
+template <int NB>
+__global__ __launch_bounds__(512) void attn_bwd_one_g_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
+                                                            const half_t* __restrict__ datt, const float* __restrict__ lse,
+                                                            half_t* __restrict__ dqkv, int T, int heads) {
+  APH_DYN_SMEM(smem);
+  half_t* Qs = reinterpret_cast<half_t*>(smem);          // current query block, row-major
+  half_t* Os = Qs + 4096;                                // dO of the block, row-major
+  half_t* Qt = Os + 4096;                                // transposed slot-permuted images of the two
+  half_t* Ot = Qt + 4096;
+  half_t* Kt = Ot + 4096;                                // K^T, NB tiles of [64 d][64 key slots]
+  half_t* dSb = Kt + NB * 4096;                          // dS^T of the block: NB tiles of [64 queries][64 key slots]
+  float* Ls = reinterpret_cast<float*>(dSb + NB * 4096);
+  float* Ds = Ls + 64;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+  const int D = heads * 64, ld = 3 * D;
+  const half_t* base = qkv + (size_t)s * T * ld + h * 64;
+  const half_t* dob = datt + (size_t)s * T * D + h * 64;
+  const half_t* ob = att + (size_t)s * T * D + h * 64;
+  half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < NB * 64; idx += 512) atg_stage<NB>(base + D, ld, T, nullptr, Kt, idx);
+  for (int i = tid; i < NB * 512; i += 512) reinterpret_cast<half8*>(dSb)[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int NJ = (4 * NB + 7) / 8;                   // key tiles per wave
+  half8 kf[NJ][2], vf[NJ][2];
+  f32x4 ok[NJ][4], ov[NJ][4];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = (wave + 8 * jj) * 16 + c16;
+    const bool live = j < T;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      kf[jj][kd] = ld_frag_global(base + (size_t)(live ? j : 0) * ld + D + kd * 32 + g * 8, live);
+      vf[jj][kd] = ld_frag_global(base + (size_t)(live ? j : 0) * ld + 2 * D + kd * 32 + g * 8, live);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { ok[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  for (int blk = 0; blk * 64 < T; ++blk) {
+    const int q0 = blk * 64;
+    // stage the block's Q / dO rows; the other threads form lse * log2 e and D_i = dO_i . O_i of its rows
+    if (tid < 64) at_stage_item(base + (size_t)q0 * ld, ld, T - q0, tid, Qs, Qt);
+    else if (tid < 128) at_stage_item(dob + (size_t)q0 * D, D, T - q0, tid - 64, Os, Ot);
+    else if (tid < 384) {
+      const int t = tid - 128, row = t >> 2, q4 = t & 3, i = q0 + row;
+      const bool live = i < T;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const half8 a = ld_frag_global(ob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
+        const half8 b = ld_frag_global(dob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)b[e];
+      }
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      if (q4 == 0) {
+        Ds[row] = d;
+        Ls[row] = live ? lse[((size_t)s * heads + h) * T + i] * kLog2e : 0.f;
+      }
+    }
+    __syncthreads();                                     // the block's images are complete (and every wave has left the previous block's dQ phase)
+    // ---- phase 1: this wave's key tiles against the block's queries -> dK, dV (registers), dS^T (LDS)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int jt = wave + 8 * jj;
+      if (jt * 16 < T) {
+        const int key = jt * 16 + c16, sl = slot_of(key & 63);
+        half_t* dst = dSb + (key >> 6) * 4096 + (sl & 7);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          if (q0 + qb * 32 < T) {
+            f32x4 sq[2], dq[2], pp[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              sq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+              const int t16 = qb * 32 + u * 16;
+#pragma unroll
+              for (int kd = 0; kd < 2; ++kd) {
+                sq[u] = mfma_16x16x32_f16(at_frag(Qs, t16 + c16, kd * 4 + g), kf[jj][kd], sq[u]);
+                dq[u] = mfma_16x16x32_f16(at_frag(Os, t16 + c16, kd * 4 + g), vf[jj][kd], dq[u]);
+              }
+              const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + t16 + g * 4);
+              const f32x4 D4 = *reinterpret_cast<const f32x4*>(Ds + t16 + g * 4);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float p = at_p(sq[u][r], L4[r]);
+                pp[u][r] = p;
+                sq[u][r] = at_ds(p, dq[u][r], D4[r]);     // dS
+              }
+            }
+            const half8 pf = pack8(pp[0], pp[1]), sf = pack8(sq[0], sq[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              ov[jj][dt] = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, qb * 4 + g), pf, ov[jj][dt]);
+              ok[jj][dt] = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, qb * 4 + g), sf, ok[jj][dt]);
+            }
+            // dS of (query qb*32 + u*16 + 4 g + r, this lane's key) -> [query][key slot]
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dst[at_off(qb * 32 + u * 16 + 4 * g + r, sl >> 3)] = sf[u * 4 + r];
+          }
+        }
+      }
+    }
+    __syncthreads();                                     // dS^T of the block is complete
+    // ---- phase 2: dQ^T = K^T dS^T of the block: wave -> query tile wave & 3, d tiles 2 (wave >> 2) and + 1
+    const int qt = wave & 3, dt0 = 2 * (wave >> 2);
+    if (q0 + qt * 16 < T) {
+      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < 2 * NB; ++kb) {
+        if (kb * 32 < T) {
+          const half8 df = at_frag(dSb + (kb >> 1) * 4096, qt * 16 + c16, (kb & 1) * 4 + g);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) o[e] = mfma_16x16x32_f16(at_frag(Kt + (kb >> 1) * 4096, (dt0 + e) * 16 + c16, (kb & 1) * 4 + g), df, o[e]);
+        }
+      }
+      const int i = q0 + qt * 16 + c16;
+      if (i < T) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) store_h4(dbase + (size_t)i * ld + (dt0 + e) * 16 + g * 4, o[e][0], o[e][1], o[e][2], o[e][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = (wave + 8 * jj) * 16 + c16;
+    if (j < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[jj][dt][0], ok[jj][dt][1], ok[jj][dt][2], ok[jj][dt][3]);
+        store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[jj][dt][0], ov[jj][dt][1], ov[jj][dt][2], ov[jj][dt][3]);
+      }
+    }
+  }
+}
+
 }  // namespace aph

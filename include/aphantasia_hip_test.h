@@ -57,6 +57,9 @@ int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
+/* Attention backward for sequences of 65 ... 256 tokens (ViT-B/16): 1 = one kernel that forms the probabilities and dS once and hands dS to
+ * the dQ contraction through LDS (default), 0 = the dQ kernel + dK/dV kernel pair (each recomputes them).  Returns the previous value. */
+int aph_attn_set_bwd_one(int on);
 /* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
  * GEMMs over K <= 1024 of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
