@@ -588,8 +588,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
 // takes the other layout THROUGH LDS: for one 64-query block at a time every wave writes its dS entries, f16, into a [64 queries][T key slots]
 // image (the slot order of the K^T image), and after a barrier the eight waves form the block's dQ^T = K^T dS^T tiles from that image and the
 // resident K^T -- 2 bytes written and read per score instead of a second exponential, two more MFMAs and a dozen VALU slots.
-// The row term D_i = dO_i . O_i is formed while the block's Q / dO rows are staged (threads that are not staging); a block's rows are
-// requested one phase ahead (register prefetch under the dQ phase, whose register needs are small).
+// The row term D_i = dO_i . O_i is formed while the block's Q / dO rows are staged (threads that are not staging).
+// (Measured and rejected: requesting the NEXT block's rows into registers right behind the phase-1 barrier so that they land under the dQ
+// phase -- 120.9 against 113.3 us at C4's shape, profiles/r05_attn_bwd_one.txt: the in-order vmcnt ties the dQ stores to those loads.)
 // LDS: Q, dO row-major + transposed for ONE 64-query block (32 KiB), K^T (8 NB KiB), dS^T (8 NB KiB), lse / D: 96.5 KiB at NB = 4.
 // Two barriers per query block.  Keys / queries past T: as above (zero operand rows, finite p and dS); the dS^T image starts zeroed, so the
 // slots of key tiles nobody computes contribute nothing.
@@ -630,41 +631,28 @@ __global__ __launch_bounds__(512) void attn_bwd_one_g_kernel(const half_t* __res
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { ok[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
-  // The next block's rows are REQUESTED right behind the barrier that ends phase 1 and land during phase 2 (whose register needs are small):
-  // waves 0 / 1 hold Q / dO rows (one staging item per lane), waves 2 ... 5 a quarter row of O and dO each for the row dots.
-  const int role = tid < 64 ? 0 : tid < 128 ? 1 : tid < 384 ? 2 : 3;
-  half8 rows[8];
-  float lse_r = 0.f;
-  auto request = [&](int q0) {
-    if (role == 0) at_stage_load(base + (size_t)q0 * ld, ld, T - q0, tid, rows);
-    else if (role == 1) at_stage_load(dob + (size_t)q0 * D, D, T - q0, tid - 64, rows);
-    else if (role == 2) {
-      const int t = tid - 128, row = t >> 2, q4 = t & 3, i = q0 + row;
-      const bool live = i < T;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        rows[c] = ld_frag_global(ob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
-        rows[2 + c] = ld_frag_global(dob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
-      }
-      lse_r = (live && q4 == 0) ? lse[((size_t)s * heads + h) * T + i] * kLog2e : 0.f;
-    }
-  };
-  request(0);
   for (int blk = 0; blk * 64 < T; ++blk) {
     const int q0 = blk * 64;
-    // the block's images from the registers requested one phase ago: Q / dO row-major + transposed, lse * log2 e, D_i = dO_i . O_i
-    if (role == 0) at_stage_store(rows, tid, Qs, Qt);
-    else if (role == 1) at_stage_store(rows, tid - 64, Os, Ot);
-    else if (role == 2) {
-      const int t = tid - 128, row = t >> 2, q4 = t & 3;
+    // stage the block's Q / dO rows; the other threads form lse * log2 e and D_i = dO_i . O_i of its rows
+    if (tid < 64) at_stage_item(base + (size_t)q0 * ld, ld, T - q0, tid, Qs, Qt);
+    else if (tid < 128) at_stage_item(dob + (size_t)q0 * D, D, T - q0, tid - 64, Os, Ot);
+    else if (tid < 384) {
+      const int t = tid - 128, row = t >> 2, q4 = t & 3, i = q0 + row;
+      const bool live = i < T;
       float d = 0.f;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c) {
+        const half8 a = ld_frag_global(ob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
+        const half8 b = ld_frag_global(dob + (size_t)(live ? i : 0) * D + q4 * 16 + c * 8, live);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d += (float)rows[c][e] * (float)rows[2 + c][e];
+        for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)b[e];
+      }
       d += __shfl_xor(d, 1);
       d += __shfl_xor(d, 2);
-      if (q4 == 0) { Ds[row] = d; Ls[row] = lse_r; }
+      if (q4 == 0) {
+        Ds[row] = d;
+        Ls[row] = live ? lse[((size_t)s * heads + h) * T + i] * kLog2e : 0.f;
+      }
     }
     __syncthreads();                                     // the block's images are complete (and every wave has left the previous block's dQ phase)
     // ---- phase 1: this wave's key tiles against the block's queries -> dK, dV (registers), dS^T (LDS)
@@ -712,7 +700,6 @@ __global__ __launch_bounds__(512) void attn_bwd_one_g_kernel(const half_t* __res
       }
     }
     __syncthreads();                                     // dS^T of the block is complete
-    if (q0 + 64 < T) request(q0 + 64);
     // ---- phase 2: dQ^T = K^T dS^T of the block: wave -> query tile wave & 3, d tiles 2 (wave >> 2) and + 1
     const int qt = wave & 3, dt0 = 2 * (wave >> 2);
     if (q0 + qt * 16 < T) {
