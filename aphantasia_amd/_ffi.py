@@ -74,7 +74,6 @@ _PROTOTYPES = {
     'aph_gemm_set_ws_min_tiles': (c_int, [c_int]),
     'aph_gemm_set_ws_pgroup': (c_int, [c_int]),
     'aph_gemm_set_rs': (c_int, [c_int]),
-    'aph_attn_set_bwd_one': (c_int, [c_int]),
     'aph_mfma_rate': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'aph_gemm_rs_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_gemm_ws_probe': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
@@ -100,6 +99,7 @@ _EXPERIMENT_PROTOTYPES = {
     'aph_vit_set_fused_max_rows': (c_int, [c_int]),
     'aph_vit_set_fused_attn': (c_int, [c_int]),
     'aph_gemm_pack_frag': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'aph_attn_set_bwd_one': (c_int, [c_int]),
 }
 
 

@@ -239,17 +239,24 @@ void launch_attn_fwd_g(const AttnArgs& a, hipStream_t st) {
   APH_ALLOW_SMEM((attn_fwd_mfma_g_kernel<NB>), smem);
   APH_LAUNCH((attn_fwd_mfma_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem, st, a.qkv, a.att, a.lse, a.T, a.heads);
 }
-// blocked backward (64 < T <= 256): 1 = the one-kernel form (P and dS formed once: attn_bwd_one_g_kernel), 0 = the dQ + dK/dV kernel pair
+// blocked backward (64 < T <= 256): one kernel, P and dS formed once (attn_bwd_one_g_kernel); -DAPH_EXPERIMENTS builds can switch back to
+// the dQ + dK/dV kernel pair it superseded (aph_attn_set_bwd_one(0))
+#ifdef APH_EXPERIMENTS
 int g_attn_bwd_one = 1;
+#endif
 template <int NB>
 void launch_attn_bwd_g(const AttnArgs& a, hipStream_t st) {
-  if (g_attn_bwd_one) {
+#ifdef APH_EXPERIMENTS
+  if (g_attn_bwd_one)
+#endif
+  {
     constexpr size_t smem = (size_t)(4 + 2 * NB) * 8192 + 2 * 64 * sizeof(float);
     APH_ALLOW_SMEM((attn_bwd_one_g_kernel<NB>), smem);
     APH_LAUNCH((attn_bwd_one_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem, st, a.qkv, (const half_t*)a.att, a.datt, (const float*)a.lse, a.dqkv,
                a.T, a.heads);
     return;
   }
+#ifdef APH_EXPERIMENTS
   constexpr size_t smem_q = (size_t)3 * NB * 8192, smem_kv = (size_t)4 * NB * 8192 + 2 * NB * 64 * sizeof(float);
   APH_ALLOW_SMEM((attn_bwd_dq_g_kernel<NB>), smem_q);
   APH_ALLOW_SMEM((attn_bwd_dkv_g_kernel<NB>), smem_kv);
@@ -257,6 +264,7 @@ void launch_attn_bwd_g(const AttnArgs& a, hipStream_t st) {
              a.dqkv, a.T, a.heads);
   APH_LAUNCH((attn_bwd_dkv_g_kernel<NB>), dim3(a.S * a.heads), dim3(512), smem_kv, st, a.qkv, a.datt, (const float*)a.lse, (const float*)a.delta,
              a.dqkv, a.T, a.heads);
+#endif
 }
 void launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   const int T = a.T;
@@ -595,12 +603,14 @@ int aph_gemm_set_ws_min_tiles(int tiles) {
 
 // small-M GEMMs (below the wave-specialised kernel's threshold) on the register-staged kernels of vit_gemm_rs.h (1, default) or on the shared-ring
 // tile configurations of vit_gemm.h (0).  Returns the previous value.
+#ifdef APH_EXPERIMENTS
 // blocked attention backward (64 < tokens <= 256): 1 = one kernel (default), 0 = the dQ + dK/dV pair.  Returns the previous value.
 int aph_attn_set_bwd_one(int on) {
   const int prev = g_attn_bwd_one;
   g_attn_bwd_one = on ? 1 : 0;
   return prev;
 }
+#endif
 int aph_gemm_set_rs(int mode) {
   const int prev = gemm_rs_mode();
   gemm_rs_mode() = mode < 0 ? 0 : (mode > 2 ? 2 : mode);

@@ -431,6 +431,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __re
   }
 }
 
+#ifdef APH_EXPERIMENTS       // the round-3 / round-4 backward as two kernels, each recomputing P and dS: superseded by attn_bwd_one_g_kernel below
+                             // (131-139 -> 113-115 us at C4's shape, profiles/r05_attn_bwd_one.txt); kept compilable for A/B runs only
 // dQ (query tiles stationary) + the row dots delta_i = dO_i . O_i, written for the dK/dV kernel
 template <int NB>
 __global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ att,
@@ -578,6 +580,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
     }
   }
 }
+
+#endif  // APH_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------
 // [r5] The blocked backward as ONE kernel: P = exp(S / 8 - lse) and dS are formed ONCE per (query, key).

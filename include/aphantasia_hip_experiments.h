@@ -18,6 +18,9 @@ int aph_vit_set_fused_max_rows(int rows);
  * as its own launch), 1 = while cuts x heads workgroups fit the chip in one round (default), 2 = always.  Returns the previous value. */
 int aph_vit_set_fused_attn(int mode);
 int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream);      /* experiment: fragment-major weights (probe kind 2) */
+/* Attention backward for sequences of 65 ... 256 tokens (ViT-B/16): 1 = one kernel that forms the probabilities and dS once and hands dS to
+ * the dQ contraction through LDS (default), 0 = the dQ kernel + dK/dV kernel pair (each recomputes them).  Returns the previous value. */
+int aph_attn_set_bwd_one(int on);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ int aph_vit_profile(aph_vit* vit, int on);
 int aph_vit_profile_read(aph_vit* vit, double* ms_total, long long* launches, double* flops);
 /* The ViT's attention kernels alone (head dim 64, T <= 256): mode 0 = forward (qkv -> att, lse), mode 1 = backward
  * ((qkv, att, lse, datt) -> dqkv).  qkv / dqkv [S*T, 3*heads*64] f16 (q | k | v column blocks), att / datt [S*T, heads*64] f16,
- * lse [S*heads*T] f32 (log-sum-exp of the scores / 8); d_delta: S*heads*T floats of scratch for the backward when T > 64. */
+ * lse [S*heads*T] f32 (log-sum-exp of the scores / 8); d_delta: S*heads*T floats of scratch for the backward when T > 64 (only the two-kernel
+ * backward of -DAPH_EXPERIMENTS builds writes it; still required for call compatibility). */
 int aph_attn_test(const void* d_qkv, void* d_att, float* d_lse, const void* d_datt, float* d_delta, void* d_dqkv, int S, int T, int heads,
                   int mode, void* stream);
 /* C[M,N] f32 = A[M,K] f16 * Bt[N,K]^T f16 (N % 128 == 0, K % 64 == 0): the ViT GEMM core with the automatic tile choice */
@@ -57,9 +58,6 @@ int aph_vit_set_fuse_ln(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* Attention backward for sequences of 65 ... 256 tokens (ViT-B/16): 1 = one kernel that forms the probabilities and dS once and hands dS to
- * the dQ contraction through LDS (default), 0 = the dQ kernel + dK/dV kernel pair (each recomputes them).  Returns the previous value. */
-int aph_attn_set_bwd_one(int on);
 /* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
  * GEMMs over K <= 1024 of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
  * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
