@@ -783,10 +783,14 @@ inline int& gemm_ws_min_tiles() {
   return v;
 }
 
-// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows over K <= 1024
-// (the K = width class-row GEMMs of the last block, a one-cut batch): one launch with an ordered in-kernel reduction instead of a split-K
-// launch plus its reduce launch, 7.2-8.0 against 10.9-11.3 us in the 24-cut step.  Over K = 3072 the two-pass split-K stays: its 48
-// workgroups pull the cold weight matrix through four times as many CUs (11.3 against 20 us, profiles/r05_kernel_stats_s26_fused_v4.csv);
+// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for DENSE GEMMs of at most 128 rows over
+// K <= 1024 (a batch of one or two cuts: C1): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce
+// launch (C1 577 -> 726 steps/s).  Over K = 3072 the two-pass split-K stays: its 48 workgroups pull the cold weight matrix through four
+// times as many CUs (11.3 against 20 us, profiles/r05_kernel_stats_s26_fused_v4.csv).  The strided class-row GEMMs of the last block
+// (lda = T x width) stay on the two-pass kernels as well: 3-4 us each faster on this kernel at 24 cuts, but the stress-weight loss curve of
+// the split-precision mode -- a chaotic amplifier of rounding ORDER, DESIGN.md section 4 *Precision* -- sits at 2.6e-4 with the old order
+// and 7.6e-4 with this one (profiles/r05_stress_rs_ab.txt; the kernel itself is the more accurate of the two against fp64), and the margin
+// under north_star's 1e-3 is worth more than 0.7 % of a shard's step;
 // 2 = every shape below the wave-specialised kernel's threshold (measured SLOWER than the ring kernels from M ~ 1200 up: same file; kept for
 // A/B runs); 0 = never.  aph_gemm_set_rs().
 template <class Epi>
@@ -804,7 +808,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (M <= 128 && K <= 1024)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
+  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (M <= 128 && K <= 1024 && lda == K)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
       launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
     return;
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);

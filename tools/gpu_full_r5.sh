@@ -14,7 +14,7 @@ for c in c1 c3 c4 c5; do timeout 300 python bench.py --config $c --steps 30 --no
 export TMPDIR=/tmp
 for c in c2 c4; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_$c -- python $R/bench.py --config $c --steps 20 --no-cpu-baseline --no-roofline --no-legs > $O/${TAG}_prof_$c.log 2>&1)
-  python tools/prof_summary.py $O/${TAG}_prof_$c 25 $O/${TAG}_kernel_stats_$c.csv 48 > $O/${TAG}_kernel_stats_$c.txt 2>&1
+  python tools/prof_summary.py $O/${TAG}_prof_$c 65 $O/${TAG}_kernel_stats_$c.csv 48 > $O/${TAG}_kernel_stats_$c.txt 2>&1
 done
 B="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-legs --no-graph"
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- $B > $O/${TAG}_pmc_fetch.log 2>&1)
