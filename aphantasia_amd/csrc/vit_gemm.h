@@ -783,18 +783,20 @@ inline int& gemm_ws_min_tiles() {
   return v;
 }
 
-// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for DENSE GEMMs of at most 128 rows over
-// K <= 1024 (a batch of one or two cuts: C1): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce
-// launch (C1 577 -> 726 steps/s).  Over K = 3072 the two-pass split-K stays: its 48 workgroups pull the cold weight matrix through four
-// times as many CUs (11.3 against 20 us, profiles/r05_kernel_stats_s26_fused_v4.csv).  The strided class-row GEMMs of the last block
-// (lda = T x width) stay on the two-pass kernels as well: 3-4 us each faster on this kernel at 24 cuts, but the stress-weight loss curve of
-// the split-precision mode -- a chaotic amplifier of rounding ORDER, DESIGN.md section 4 *Precision* -- sits at 2.6e-4 with the old order
-// and 7.6e-4 with this one (profiles/r05_stress_rs_ab.txt; the kernel itself is the more accurate of the two against fp64), and the margin
-// under north_star's 1e-3 is worth more than 0.7 % of a shard's step;
-// 2 = every shape below the wave-specialised kernel's threshold (measured SLOWER than the ring kernels from M ~ 1200 up: same file; kept for
-// A/B runs); 0 = never.  aph_gemm_set_rs().
-template <class Epi>
-inline bool launch_gemm_rs_auto(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st, bool wide);   // vit_gemm_rs.h
+// The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows over
+// K <= 1024 WHEN THE WHOLE BATCH IS THAT SMALL (gemm_rs_small_batch(), set by the ViT entry points from cuts x tokens: one or two cuts,
+// C1): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce launch (C1 577 -> 726 steps/s).  Over
+// K = 3072 the two-pass split-K stays: its 48 workgroups pull the cold weight matrix through four times as many CUs (11.3 against 20 us,
+// profiles/r05_kernel_stats_s26_fused_v4.csv).  The class-row GEMMs of a LARGER batch's last block (M = cuts) stay on the two-pass
+// kernels as well: 3-4 us each faster on this kernel at 24 cuts, but the stress-weight loss curve is a chaotic amplifier of rounding ORDER
+// (DESIGN.md section 4 *Precision*): three summation orders of those few GEMMs gave 2.6e-4 / 7.6e-4 / 1.04e-3 in the split-precision mode
+// (profiles/r05_stress_rs_ab.txt, r05_stress_rs_dense.txt; against fp64 this kernel is the more accurate of the two), and the order with
+// the margin under north_star's 1e-3 is worth more than 0.7 % of a shard's step;
+// 2 = every shape the register-staged kernels address (the A/B switch of bench.py --vit-path rs and the test hook); 0 = off.
+inline bool& gemm_rs_small_batch() {
+  static bool small = true;  // stand-alone GEMM calls (the test hook) count as small batches
+  return small;
+}
 inline int& gemm_rs_mode() {
   static int v = 1;
   return v;
@@ -808,7 +810,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (M <= 128 && K <= 1024 && lda == K)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
+  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (gemm_rs_small_batch() && M <= 128 && K <= 1024)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
       launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
     return;
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);
