@@ -409,13 +409,13 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
 // i.e. with ~22 operand bits on the two activations whose f16 rounding dominates the input-gradient error on weights with realistic
 // dynamic range (profiles/r04_precision_attribution.txt).  Everything else, the backward included, is unchanged.
 static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_enc, bool hilo, void* stream_) {
-  gemm_rs_small_batch() = (long long)S * v->T <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   if (!v || !d_patches || !d_enc) return aph_fail(APH_ERR_ARG, "aph_vit_forward: null argument");
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_forward: batch %d outside 1..%d", S, v->max_batch);
   if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_forward: weights not fully loaded (%d tensors)", v->n_set);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   const int kx = hilo ? 2 : 1;
+  gemm_rs_small_batch() = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st, kx);
   const bool fuse = g_fuse_ln != 0;
   const bool blk = !hilo && vit_fused(v, S);          // fused block kernels: LayerNorm inside the QKV / fc1 launches, attention behind the QKV GEMM
@@ -473,11 +473,11 @@ int aph_vit_forward_hilo(aph_vit* v, const void* d_patches_hilo, int S, float* d
 // input-gradient of the last aph_vit_forward: d_genc f32 [S, output_dim] (already multiplied by the caller's
 // loss scale) -> d_patch_grad f32 [S*P, 3*patch*patch] multiplied by out_scale (pass 1/loss_scale).
 static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_patch_grad, bool grad_f16, float out_scale, void* stream_) {
-  gemm_rs_small_batch() = (long long)S * v->T <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   if (!v || !d_genc || !d_patch_grad) return aph_fail(APH_ERR_ARG, "aph_vit_backward: null argument");
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
+  gemm_rs_small_batch() = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
   // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
   const bool fuse = g_fuse_ln != 0;      // (then the last block's ln_1 backward takes its residual from the class rows only: no fill)
