@@ -424,6 +424,10 @@ class Engine:
             self._graphs = None
             print(' fp16 overflow in the backward pass: %d step(s) skipped so far, loss scale -> %g' % (count, self.loss_scale), flush=True)
 
+    @staticmethod
+    def _same_bits(a, b):
+        return torch.equal(a, b)
+
     def _capture(self):
         """Record the step's ~280 launches into hipGraphs (replayed per step: the host then costs three tiny H2D copies
         and one or two graph launches).  Everything the kernels read that changes per step -- crop table, augment table,
@@ -443,9 +447,10 @@ class Engine:
             print(' rank %d: capturing the step with its all-reduce into a hipGraph failed (%s): multi-rank steps stay eager' % (self.rank, e), flush=True)
             self.use_graph, self._graphs = False, None
             return
-        if self.world > 1 and not getattr(self, '_graph_checked', False):
+        if self._reduce and self.comm is not None and not getattr(self, '_graph_checked', False):
             # one-time self-check: ONE eager step and ONE replay from the same state and the same (already uploaded) step inputs must
-            # leave the same bits in the parameters, on every rank
+            # leave the same bits in the parameters, on every rank (a one-rank communicator runs it too: that is how a one-GPU box
+            # covers this code, tests/test_gpu_comm.py)
             state = [t for t in (self.params, self.m, self.v, self.vmax, self.guard) if t is not None]
             snap = [t.detach().clone() for t in state]
 
@@ -460,7 +465,7 @@ class Engine:
                 ref = self.params.detach().clone()
                 restore()
                 g1.replay()
-                same = torch.equal(ref, self.params.detach())
+                same = self._same_bits(ref, self.params.detach())
                 restore()
                 flag = torch.tensor([1.0 if same else 0.0], device=self.dev)
                 self.comm.all_reduce_(flag, ops._stream(flag))
@@ -473,7 +478,7 @@ class Engine:
                 return
             self._graph_checked = True
             if int(round(float(flag))) != self.world:
-                print(' rank %d: the captured multi-rank step did not reproduce an eager step bit for bit (this rank: %s): steps stay eager'
+                print(' rank %d: the captured step with its all-reduce did not reproduce an eager step bit for bit (this rank: %s): steps stay eager'
                       % (self.rank, 'same' if same else 'DIFFERENT'), flush=True)
                 self.use_graph, self._graphs = False, None
                 return

@@ -58,13 +58,25 @@ def test_step_with_in_graph_allreduce_matches_plain_step():
             if i == 4:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
+        run.last = eng
         return eng.params.clone(), eng.grad.clone(), [float(l) for l in losses[-1:]]
     a = run(None, False)
     b = run(c, False)
     d = run(c, True)
+    # the capture self-check (one eager step against one replay from the same state, agreed through the communicator) ran and passed
+    assert run.last._graph_checked and run.last.use_graph and run.last._graphs is not None
     for x, y in ((a, b), (a, d)):
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and x[2] == y[2]
     assert torch.isfinite(a[0]).all()
+    # a self-check that FAILS: the engine restores the state it started the check from, stays eager, and the run is still the same run
+    saved = Engine._same_bits
+    Engine._same_bits = staticmethod(lambda p, q: False)
+    try:
+        e = run(c, True)
+    finally:
+        Engine._same_bits = saved
+    assert run.last._graph_checked and not run.last.use_graph and run.last._graphs is None
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and a[2] == e[2]
 
 
 def _rank_main(rank, world, port, ret):
