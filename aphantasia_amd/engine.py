@@ -435,16 +435,39 @@ class Engine:
         torch.cuda.synchronize()
         self._vit_handle = self.visual.handle
         g1 = torch.cuda.CUDAGraph()
+        with_comm = self._reduce and self.comm is not None
+        captured = True
         try:
-            with torch.cuda.graph(g1):
+            # with a collective in the graph, only THIS thread's calls are policed during capture: a collective library's helper threads
+            # may call the runtime meanwhile (the default 'global' mode would fail the capture, or their call, for that)
+            with torch.cuda.graph(g1, **({'capture_error_mode': 'thread_local'} if with_comm else {})):
                 self._enqueue_grad(None)
                 if self._reduce:
                     self._all_reduce()         # (only with a direct RCCL comm: the collective is a node of the step's graph)
                 self._enqueue_adam()
         except Exception as e:                 # e.g. a collective library that refuses stream capture: stay eager, loudly
-            if self.world == 1:
+            if not with_comm:
                 raise
-            print(' rank %d: capturing the step with its all-reduce into a hipGraph failed (%s): multi-rank steps stay eager' % (self.rank, e), flush=True)
+            print(' rank %d: capturing the step with its all-reduce into a hipGraph failed (%s): steps stay eager' % (self.rank, e), flush=True)
+            captured = False
+        if with_comm and not getattr(self, '_graph_checked', False):
+            # the ranks agree FIRST on whether every one of them holds a graph (a rank that left here alone would leave the others waiting in
+            # the check's collectives): all or none
+            try:
+                flag = torch.tensor([1.0 if captured else 0.0], device=self.dev)
+                self.comm.all_reduce_(flag, ops._stream(flag))
+                torch.cuda.synchronize()
+                everyone = int(round(float(flag))) == self.world
+            except Exception as e:
+                print(' rank %d: agreeing on the captured step failed (%s): steps stay eager' % (self.rank, e), flush=True)
+                everyone = False
+            if not everyone:
+                if captured:
+                    print(' rank %d: another rank could not capture its step: steps stay eager on every rank' % self.rank, flush=True)
+                self._graph_checked = True
+                self.use_graph, self._graphs = False, None
+                return
+        elif not captured:
             self.use_graph, self._graphs = False, None
             return
         if self._reduce and self.comm is not None and not getattr(self, '_graph_checked', False):
