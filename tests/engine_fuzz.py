@@ -41,7 +41,8 @@ def draw_case(rng, force=None):
     sharp = float(rng.choice([0, 0, 0.3])); expand = float(rng.choice([0, 0, 0.5])) if sim != 'ang' else 0.0
     enforce = float(rng.choice([0, 0, 0.1])) if sim != 'ang' else 0.0
     wave = str(rng.choice(WAVES))
-    case = dict(H=H, W=W, S=S, sim=sim, opt=opt, align=align, kind=kind, fast=fast, sharp=sharp, expand=expand, enforce=enforce, wave=wave)
+    precise = bool(rng.integers(0, 2))        # [r5] the split-precision ViT forward (the CLI's default) or f16 operands everywhere (drawn last: the other fields of a seed stay what they were)
+    case = dict(precise=precise, H=H, W=W, S=S, sim=sim, opt=opt, align=align, kind=kind, fast=fast, sharp=sharp, expand=expand, enforce=enforce, wave=wave)
     case.update(force or {})
     if case['sim'] == 'ang':
         case['expand'] = case['enforce'] = 0.0
@@ -63,7 +64,7 @@ def run_case(model, case, seed, dev='cuda', tol=2e-3, steps=2):
         seed_all(seed)
         tgt = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
         trf = transforms.transforms_fast if fast else transforms.normalize()
-        kw = dict(sim=sim, optimizer=opt, align=align, macro=0.4, sharp=sharp, expand=expand, enforce=enforce, transform=trf, rng='reference')
+        kw = dict(sim=sim, optimizer=opt, align=align, macro=0.4, sharp=sharp, expand=expand, enforce=enforce, transform=trf, rng='reference', precise=bool(case.get('precise', False)))
         okw = dict(sim=sim, optimizer=opt, align=align, sharp=sharp, expand=expand, enforce=enforce)
         if kind == 'dwt':
             from aphantasia_amd.image import dwt_image

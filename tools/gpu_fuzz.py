@@ -31,9 +31,11 @@ for it in range(20):
     attempt('attention', K.check_attention, None, 'cuda', S=int(rng.integers(1, 40)), T=int(rng.integers(1, 257)), heads=int(rng.integers(1, 13)), seed=it)
 for it in range(40):
     M = int(rng.integers(1, 12000)); N = 128 * int(rng.integers(1, 25)); Kk = 64 * int(rng.integers(1, 49))
-    cfg = int(rng.choice([0, 1, 2, 4, 8, 9, 10, 11, 12, 22, 24]))
-    if cfg == 4 and N % 256: N += 128
-    attempt('gemm', K.check_gemm, None, 'cuda', [(M, N, Kk)], tile_cfg=cfg, variants=(0, 1) if cfg in (0, 1, 2, 4, 10) else (0,))
+    cfg = int(rng.choice([0, 1, 2, 5, 8, 9, 10, 11, 12, 22, 24]))
+    attempt('gemm', K.check_gemm, None, 'cuda', [(M, N, Kk)], tile_cfg=cfg, variants=(0, 1) if cfg in (0, 1, 2, 10) else (0,))
+for it in range(24):            # [r5] small batches: the register-staged split-K kernel (14 / 15) and what the heuristic picks for them (0)
+    M = int(rng.integers(1, 200)); N = 64 * int(rng.integers(1, 49)); Kk = int(rng.choice([256, 768, 1024, 2304, 3072]))
+    attempt('gemm-small', K.check_gemm, None, 'cuda', [(M, N, Kk)], tile_cfg=int(rng.choice([0, 14, 15])), variants=(0,))
 for it in range(12):
     h = int(rng.integers(8, 900)); w = int(rng.integers(8, 1400))
     attempt('synth', K.check_synth_vs_oracle, None, 'cuda', h, w, 1.0 + 0.1 * (it % 2), with_shift=bool(it % 2))
