@@ -686,7 +686,8 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
       if (b0 + NBC < nlist) phase0(b0 + NBC, cur ^ 1);
       // ---- phase 2: row pass, cuts in list order
       // ([r5] measured and not adopted, profiles/r05_sampler_pipelined_ab.txt: the entries of groups of two cuts loaded two groups ahead into a
-      // register ring -- unconditional clamped loads, partial vmcnt waits in the ISA -- 293.6 -> 301.5 us: this pass does not wait for L2)
+      // register ring -- unconditional clamped loads, partial vmcnt waits in the ISA -- 293.6 -> 301.5 us: this pass does not wait for L2; and the
+      // taps of a (column, cut) read back to back without the per-tap zero-weight skips: 296.6 -> 310.4 us -- every skipped tap is three LDS reads)
       if (!(dbg & 2)) {
         // four cuts x CPT columns at a time: the first offset and the four weights of every column-tap entry (20 of its 32 bytes) are
         // loaded together, then accumulated per column in list order
