@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 5: crop adjoint with pipelined entry loads against the previous build, same box, alternating
+# (record of a rejected experiment: tools/exp/libbase_sampler.so was the library built from the committed sampler.hip, the in-tree library the
+# variant -- neither the variant source nor that .so is kept; profiles/r05_sampler_pipelined_ab.txt has the numbers and sampler.hip a comment)
 mkdir -p gpurun_out
 {
 for rep in 1 2; do
