@@ -505,3 +505,22 @@ def test_frame_writer_matches_checkout_arithmetic(tmp_path):
         back = np.asarray(Image.open(os.path.join(tmp_path, '%d.png' % i)))                # PNG: lossless, what the pinned buffer held
         assert back.shape == (h, w, 3)
     assert np.array_equal(np.asarray(Image.open(os.path.join(tmp_path, '0.png'))), np.clip(img.cpu().numpy() * 255, 0, 255).astype(np.uint8).transpose(1, 2, 0))
+
+
+def test_frame_writer_ring_reuse_keeps_every_frame(tmp_path):
+    """[r5] More frames than the writer has ring slots, put back to back without draining: a slot's device image and pinned buffer are
+    rewritten only after the copy and the encoder thread of the frame that last used them are done (per-slot event + semaphore), so every
+    file on disk holds ITS frame (lossless PNG, frame i is the constant i)."""
+    import clip_fft
+    from PIL import Image
+    h, w = 64, 96
+    wr = clip_fft.FrameWriter(h, w)
+    n = 3 * wr.RING + 5
+    for i in range(n):
+        img = torch.full((3, h, w), (i + 0.5) / 255.0, device=DEV)
+        wr.put(img, os.path.join(tmp_path, '%03d.png' % i), 1.0)
+    wr.drain()
+    wr.close()
+    for i in range(n):
+        back = np.asarray(Image.open(os.path.join(tmp_path, '%03d.png' % i)))
+        assert back.shape == (h, w, 3) and int(back.min()) == i and int(back.max()) == i, i
