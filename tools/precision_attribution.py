@@ -47,6 +47,7 @@ from oracle.make_loss_curves import CONFIGS, seed_all, weights_of       # noqa: 
 
 LOSS_SCALE = 4096.0
 FWD = ['patches', 'w_patch', 'w_qkv', 'w_o', 'w_fc1', 'w_fc2', 'h1', 'h2', 'qkv', 'p', 'att', 'gact', 'dgelu']
+EXTRA = ['h1qk', 'h1v']      # sub-classes of h1, not part of the union sets
 BWD = ['dx16', 'du', 'dh', 'datt', 'ds', 'dqkv', 'dx0']
 
 
@@ -123,8 +124,13 @@ def make_encoder(w, cfg, q):
         for i in range(layers):
             pre = 'transformer.resblocks.%d.' % i
             h = F.layer_norm(x, (width,), wq[pre + 'ln_1.weight'], wq[pre + 'ln_1.bias'], 1e-5)
-            h = qb('dh', qf('h1', h))
-            qkv = F.linear(h, wq[pre + 'attn.in_proj_weight'], wq[pre + 'attn.in_proj_bias'])
+            if 'h1qk' in q or 'h1v' in q:          # [r5] the f16 rounding of h1 seen by the Q / K columns only, or by the V columns only
+                hr, Wi, bi = _QF.apply(h), wq[pre + 'attn.in_proj_weight'], wq[pre + 'attn.in_proj_bias']
+                qkv = torch.cat([F.linear(hr if 'h1qk' in q else h, Wi[:2 * width], bi[:2 * width]),
+                                 F.linear(hr if 'h1v' in q else h, Wi[2 * width:], bi[2 * width:])], dim=-1)
+            else:
+                h = qb('dh', qf('h1', h))
+                qkv = F.linear(h, wq[pre + 'attn.in_proj_weight'], wq[pre + 'attn.in_proj_bias'])
             qkv = qb('dqkv', qf('qkv', qkv))
             qq, k, v = qkv.split(width, dim=-1)
             qq = qq.reshape(B, T, heads, hd).transpose(1, 2) * (hd ** -0.5)
@@ -170,7 +176,8 @@ def main():
     cfg, wts = weights_of(c['weights'])
     fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'loss_curve_%s.npz' % a.name))['loss']
     split = set(s for s in a.split.split(',') if s)
-    sets = [(n, {n}) for n in FWD + BWD] + [('all_fwd', set(FWD)), ('all_bwd', set(BWD)), ('all', set(FWD + BWD))]
+    sets = [(n, {n}) for n in FWD + BWD + EXTRA] + [('all_fwd', set(FWD)), ('all_bwd', set(BWD)), ('all', set(FWD + BWD)),
+            ('all_split', set(FWD + BWD) - {'patches', 'h1'}), ('all_split_qk_only', (set(FWD + BWD) - {'patches', 'h1'}) | {'h1v'})]      # [r5] the shipped split mode; the split on the Q / K columns only
     if a.classes:
         want = a.classes.split(',')
         sets = [(n, s) for n, s in sets if n in want]
