@@ -434,7 +434,23 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
 #endif
     {
       if (!(fuse && li == 0)) launch_ln_fwd<true, false>(nv, l.x_in, l.ln1_g, l.ln1_b, v->h, M, T, nullptr, nullptr, nullptr, st, 1, nullptr, nullptr, nullptr, hilo ? 1 : 0);
-      vgemm(v, v->h, kx * D, hilo ? l.w_qkv2 : l.w_qkv, kx * D, M, 3 * D, kx * D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st, kx);
+      if (hilo) {
+        // [r5] the lo half reaches the Q and K columns only; the V columns are summed over the hi half of the [hi | lo] rows alone (the first D of
+        // the 2 D columns of A and of [W | W]).  What the lo half repairs is the cancellation in h . W on weights whose residual stream carries
+        // large common offsets: through Q and K that error is amplified by the softmax, through V it enters the block linearly next to the f16
+        // rounding V is stored with anyway (CPU model, tools/precision_attribution.py: single-step gradient error 5.2e-4 through Q / K, 1.8e-4
+        // through V; on the GPU the single-step errors of the two forms are equal, profiles/r05_split_qk_only_ab.txt).  At full batch this is ONE
+        // launch of the wave-specialised kernel with two k-loop lengths (vit_gemm_ws.h); smaller batches take two launches with the same sums.
+        const EpiF16 eq{l.qkv, 3 * D, l.b_qkv};
+        if (D % 128 == 0 && gemm_takes_ws(M, 2 * D, 3 * D, 2 * D)) {
+          vtimed(v, 2.0 * M * 3 * D * D, st, [&] { launch_gemm_ws(v->h, 2 * D, l.w_qkv2, 2 * D, M, 3 * D, 2 * D, eq, st, nullptr, D, D); });
+        } else {
+          vgemm(v, v->h, 2 * D, l.w_qkv2, 2 * D, M, 2 * D, 2 * D, eq, st, 2);
+          vgemm(v, v->h, 2 * D, l.w_qkv2 + (size_t)2 * D * 2 * D, 2 * D, M, D, D, EpiF16{l.qkv + 2 * D, 3 * D, l.b_qkv + 2 * D}, st);
+        }
+      } else {
+        vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
+      }
       launch_attn_fwd(attn_args(v, l, S), st);
     }
     // Only the class token leaves the last block (VisionTransformer.forward: ln_post(x[:, 0, :])), so everything after

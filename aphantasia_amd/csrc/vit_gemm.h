@@ -776,7 +776,7 @@ inline void launch_gemm8(const half_t* A, int lda, const half_t* Bt, int ldb, in
 //   64x64 (2 workgroups per CU)      everything smaller; split-K when only a handful of tiles exist
 template <class Epi>
 inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
-                           unsigned long long* trace = nullptr);   // vit_gemm_ws.h
+                           unsigned long long* trace = nullptr, int n_short = 0, int k_short = 0);   // vit_gemm_ws.h
 // the wave-specialised persistent kernel takes every shape with at least this many 256x128 tiles (aph_gemm_set_ws_min_tiles(); 0 = never)
 inline int& gemm_ws_min_tiles() {
   static int v = APH_GEMM_WS_MIN_TILES_DEFAULT;
@@ -802,11 +802,16 @@ inline int& gemm_rs_mode() {
   return v;
 }
 
+// does launch_gemm hand this shape to the wave-specialised persistent kernel?
+inline bool gemm_takes_ws(int M, int lda, int N, int ldb) {
+  const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
+  return gemm_ws_min_tiles() > 0 && big_tiles >= gemm_ws_min_tiles() && N <= 4096 /* GemmWS::BIAS_MAX */ && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32();
+}
 template <class Epi>
 inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
                         const SplitKSpace* sp = nullptr) {
   const int big_tiles = (N / GemmBig::BN) * ((M + GemmBig::BM - 1) / GemmBig::BM);
-  if (gemm_ws_min_tiles() > 0 && big_tiles >= gemm_ws_min_tiles() && N <= 4096 /* GemmWS::BIAS_MAX */ && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32()) {
+  if (gemm_takes_ws(M, lda, N, ldb)) {
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }

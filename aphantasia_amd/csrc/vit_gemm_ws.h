@@ -194,7 +194,8 @@ __device__ __forceinline__ void ws_wait_barrier(int ahead) {      // all but the
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_kernel(const half_t* __restrict__ A, int lda, const half_t* __restrict__ Bt,
-                                                                  int ldb, int M, int N, int K, Epi epi, int ntiles, int pgroup, unsigned long long* __restrict__ trace) {
+                                                                  int ldb, int M, int N, int K, Epi epi, int ntiles, int pgroup, unsigned long long* __restrict__ trace,
+                                                                  int ntn_short, int nk_short) {
   using F = GemmBig;                             // fragment shapes of a consumer wave: 4 x 4 MFMA tiles (64 x 64)
   APH_DYN_SMEM(smem);
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -204,19 +205,32 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   // XCD's share of the weights stays in its L2 instead of being re-fetched per row panel (284 MB of fabric traffic per fc1 launch for 136 MB
   // algorithmic).  Slower everywhere: fc1 58.3 vs 53.8 us, QKV 43.5 vs 42.0, and the single-round N = 768 shapes lose their one-tile-per-
   // workgroup balance (fc2 73.6 vs 44.4 us).  The re-fetches are served by the 256 MiB Infinity Cache and are not what bounds these launches.)
-  int tile, tile_end, tile_step;
+  // [r5] TWO tile spaces: the LONG column tiles (the first ntn - ntn_short of a row panel: k-loop over all of K) and the SHORT ones (the last
+  // ntn_short: k-loop over the first nk_short k-tiles only -- the V columns of the split-precision QKV GEMM, which take the hi half of
+  // [hi | lo] rows alone).  An XCD owns one contiguous run of each space and walks its long tiles first, then its short ones: a workgroup's
+  // positions p, p + step, ... then hold its most expensive tiles first and the cheap ones last, which is what balances the walk (456 long +
+  // 228 short tiles at C2: 228 workgroups take two long + one short = 60 k-tile rounds where the one-space walk gives 72 to some).
+  // ntn_short = 0 is the plain GEMM: one space, the walk of rounds 3 / 4.
+  const int nk = K / GEMM_BK, ntn = N / C::BN, ntm = ntiles / ntn, ntn_long = ntn - ntn_short;
+  int pos, pos_end, tile_step, lstart, sstart, nlong;
   {
-    const int nwg = gridDim.x, b = blockIdx.x, G = nwg < 8 ? nwg : 8;
-    const int q = ntiles / G, r = ntiles - q * G, xcd = b % G;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    tile_end = start + q + (xcd < r ? 1 : 0);
+    const int nwg = gridDim.x, b = blockIdx.x, G = nwg < 8 ? nwg : 8, xcd = b % G;
+    auto share = [&](int n, int& start, int& count) {
+      const int q = n / G, r = n - q * G;
+      start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      count = q + (xcd < r ? 1 : 0);
+    };
+    int nshort;
+    share(ntm * ntn_long, lstart, nlong);
+    share(ntm * ntn_short, sstart, nshort);
+    pos_end = nlong + nshort;
     tile_step = (nwg - xcd + G - 1) / G;
-    tile = start + b / G;
+    pos = b / G;
   }
-  if (tile >= tile_end) return;                  // (workgroup-uniform; does not happen with gridDim.x <= ntiles)
+  if (pos >= pos_end) return;                    // (workgroup-uniform; does not happen with gridDim.x <= ntiles)
   if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 15) * 4 + 3] = ws_realtime();   // kernel entry, chip-wide 100 MHz clock
-  const int nk = K / GEMM_BK, ntn = N / C::BN, ntm = ntiles / ntn;
-  const int U = ((tile_end - tile + tile_step - 1) / tile_step) * nk;       // k-tile units of this workgroup
+  int U = 0;                                     // k-tile units of this workgroup
+  for (int q = pos; q < pos_end; q += tile_step) U += q < nlong ? nk : nk_short;
   // Tile order inside the XCD runs: groups of `pgroup` row panels; inside a group the tiles of ONE column tile across the group's panels
   // are consecutive, then the next column tile.  The 32 workgroups of an XCD work on 32 consecutive tiles, i.e. on pgroup row panels x
   // (32 / pgroup) column tiles: with pgroup = 4 that is 1.5 MB of A panels + 1.5 MB of weight rows -- it fits the XCD's 4 MiB L2, and a
@@ -224,11 +238,15 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   // tiles = 1.3-1.8 panels x all of W, 3.5-4.7 MB at N = 2304 / 3072, which the L2 cannot hold next to the A panels: 284 MB of fabric
   // traffic per fc1 launch for 136 MB algorithmic, profiles/r03_pmc_hbm_traffic.json).  The runs and their lengths are unchanged, so the
   // balance of the persistent walk is too (what the per-XCD rectangle order of round 3 lost).
-  auto coords = [&](int t, int& tm, int& tn) {
-    const int per = pgroup * ntn, g = t / per, rem = t - g * per;
+  auto coords = [&](int q, int& tm, int& tn) -> int {          // position q of this XCD's walk -> tile coordinates; returns the tile's k-tile count
+    const bool lng = q < nlong;
+    const int t = lng ? lstart + q : sstart + (q - nlong), cols = lng ? ntn_long : ntn_short;
+    const int per = pgroup * cols, g = t / per, rem = t - g * per;
     const int left = ntm - g * pgroup, rg = left < pgroup ? left : pgroup;
     tn = rem / rg;
     tm = g * pgroup + (rem - tn * rg);
+    if (!lng) tn += ntn_long;
+    return lng ? nk : nk_short;
   };
   // the epilogue's bias vector goes to LDS behind the ring once (N <= 4096 floats); visible after the first barrier
   float* lbias = reinterpret_cast<float*>(smem + C::SMEM);
@@ -243,9 +261,10 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
     unsigned off[C::QPW];                        // per-lane byte offsets from the matrix bases, current issue tile
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(Bt);
+    int nk_it = nk;                              // k-tiles of the tile being issued
     auto setup = [&](int t) {
       int tm, tn;
-      coords(t, tm, tn);
+      nk_it = coords(t, tm, tn);
       const int n0 = tn * C::BN, m0 = tm * C::BM;
 #pragma unroll
       for (int i = 0; i < C::QPW; ++i) {
@@ -270,13 +289,13 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
         else glds16(bk + off[i], Bs + ((i - C::QAW) * C::NPROD + p) * 8 * GEMM_BK);
       }
     };
-    int it = tile, ikt = 0, ist = 0, issued = 0;
+    int it = pos, ikt = 0, ist = 0, issued = 0;
     setup(it);
     auto issue_next = [&]() {
       issue(ikt, ist);
       ist = ist == C::NSTAGE - 1 ? 0 : ist + 1;
       ++issued;
-      if (++ikt == nk) {
+      if (++ikt == nk_it) {
         ikt = 0;
         it += tile_step;
         if (issued < U) setup(it);
@@ -299,10 +318,10 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
   f32x4 acc[F::TM][F::TN];
   const int frow = lane & 15, arow = wm * 64 + frow, brow = wn * 64 + frow, fchunk = lane >> 4;
   GemmFrags<F> f0, f1;
-  int kt = 0, st = 0;
+  int kt = 0, st = 0, nk_c = nk, ti = 0;          // k-tile inside the tile, ring stage, k-tiles of the current tile, tiles done
   auto init_tile = [&](int t) {
     int tm, tn;
-    coords(t, tm, tn);
+    nk_c = coords(t, tm, tn);
     const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = tn * C::BN + wn * 64 + 4 * (lane & 15);
 #pragma unroll
     for (int mt = 0; mt < F::TM; ++mt) ws_init(epi, m4 + mt * 16, M, n4, acc[mt], lbias);
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
 #pragma unroll
       for (int nt = 0; nt < F::TN; ++nt) acc[mt][nt] = mfma_16x16x32_f16(f.a[mt], f.b[nt], acc[mt][nt]);
   };
-  init_tile(tile);                                                             // [r4] the residual epilogue's 16 loads per lane go out before the wait below:
+  init_tile(pos);                                                              // [r4] the residual epilogue's 16 loads per lane go out before the wait below:
   wait_vm_barrier<63>();                                                       // unit 0 has landed (and the bias vector is in LDS); vmcnt(63) does not wait for them
   gemm_load_frags<F>(f0, lds, lds + C::BM * GEMM_BK, arow, brow, fchunk);
   for (int u = 0; u < U; ++u) {
@@ -328,18 +347,19 @@ __global__ __launch_bounds__(C::NTHREAD, C::MIN_WAVES_PER_SIMD) void gemm_ws_ker
       gemm_load_frags<F>(f0, An, An + C::BM * GEMM_BK, arow, brow, fchunk);    // k-step 0 of unit u+1: overlaps the MFMAs below
     }
     mma(f1);                                                                   // k-step 1 of unit u
-    if (trace && kt == 0 && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 0] = ws_clock();      // first k-tile of a tile done
-    if (++kt == nk) {
-      if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 1] = ws_clock();      // (slots 14 / 15 hold the entry / exit stamps)                // main loop done
+    if (trace && kt == 0 && tid == 0 && ti < 14) trace[((size_t)blockIdx.x * 16 + ti) * 4 + 0] = ws_clock();      // first k-tile of a tile done
+    if (++kt == nk_c) {
+      if (trace && tid == 0 && ti < 14) trace[((size_t)blockIdx.x * 16 + ti) * 4 + 1] = ws_clock();      // (slots 14 / 15 hold the entry / exit stamps)                // main loop done
       // epilogue straight from the accumulators (layout: gemm_ws_brow above)
       int tm, tn;
-      coords(tile, tm, tn);
+      coords(pos, tm, tn);
       const int m4 = tm * C::BM + wm * 64 + 4 * (lane >> 4), n4 = tn * C::BN + wn * 64 + 4 * (lane & 15);
       ws_tiles(epi, m4, M, n4, acc, lbias);
-      if (trace && tid == 0 && u / nk < 14) trace[((size_t)blockIdx.x * 16 + (u / nk)) * 4 + 2] = ws_clock();                // epilogue issued
+      if (trace && tid == 0 && ti < 14) trace[((size_t)blockIdx.x * 16 + ti) * 4 + 2] = ws_clock();                // epilogue issued
       kt = 0;
-      tile += tile_step;
-      if (u + 1 < U) init_tile(tile);
+      ++ti;
+      pos += tile_step;
+      if (u + 1 < U) init_tile(pos);
     }
   }
   if (trace && tid == 0) trace[((size_t)blockIdx.x * 16 + 14) * 4 + 3] = ws_realtime();     // consumer wave 0 done
@@ -359,13 +379,13 @@ inline int gemm_ws_panel_group(int ntn, int ntm) {
 
 template <class C, class Epi>
 inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
-                               unsigned long long* trace) {
+                               unsigned long long* trace, int n_short = 0, int k_short = 0) {
   const int ntiles = (N / C::BN) * ((M + C::BM - 1) / C::BM);
   const int cus = gemm_persistent_wgs();
   const int wgs = cus > (1 << 20) ? cus : cus * C::WG_PER_CU;
   APH_ALLOW_SMEM((gemm_ws_kernel<C, Epi>), C::SMEM_TOTAL);
   APH_LAUNCH((gemm_ws_kernel<C, Epi>), dim3(ntiles < wgs ? ntiles : wgs), dim3(C::NTHREAD), C::SMEM_TOTAL, st, A, lda, Bt, ldb, M, N, K, epi, ntiles,
-             gemm_ws_panel_group(N / C::BN, (M + C::BM - 1) / C::BM), trace);
+             gemm_ws_panel_group(N / C::BN, (M + C::BM - 1) / C::BM), trace, n_short / C::BN, k_short / GEMM_BK);
 }
 // (Measured and rejected in round 4, profiles/r04_ab_gemm_flag_sync.txt: the same kernel with NO workgroup barrier in the main loop -- producers and
 // consumers handing k-tile units over through counters in LDS (ready[producer] after a counted vmcnt wait, done[consumer] after lgkmcnt(0), the
@@ -375,8 +395,9 @@ inline void launch_gemm_ws_cfg(const half_t* A, int lda, const half_t* Bt, int l
 // already wants the unit after next -- the skew the barrier forbids is paid for out of the 3-stage ring.  git show e138f33:aphantasia_amd/csrc/vit_gemm_wsf.h)
 template <class Epi>
 inline void launch_gemm_ws(const half_t* A, int lda, const half_t* Bt, int ldb, int M, int N, int K, Epi epi, hipStream_t st,
-                           unsigned long long* trace) {
-  launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace);
+                           unsigned long long* trace, int n_short, int k_short) {
+  // n_short: the LAST n_short columns (a multiple of 128) are summed over the first k_short of K only (a multiple of 64); 0 = a plain GEMM
+  launch_gemm_ws_cfg<GemmWS>(A, lda, Bt, ldb, M, N, K, epi, st, trace, n_short, k_short);
 }
 
 }  // namespace aph

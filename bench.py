@@ -499,7 +499,7 @@ def main():
             achieved = fl_t / (ms_t * 1e-3) / 1e12
             # what the hi | lo halves of the split-precision forward add on the matrix cores (QKV of every block + the patch embedding, width 768)
             m_ = cfg['model']
-            hilo_extra = 0.0 if (a.f16 or dualmod is not None or m_ not in F_T) else 2.0 * S * (F_T[m_] * 3 * 768 * 768 * 12 + F_P[m_] * 768 * F_KP[m_])
+            hilo_extra = 0.0 if (a.f16 or dualmod is not None or m_ not in F_T) else 2.0 * S * (F_T[m_] * 2 * 768 * 768 * 12 + F_P[m_] * 768 * F_KP[m_])     # (the lo half feeds the Q and K columns only)
             traffic, tsrc, stale, tmatch = (None, None, None, None)
             if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1:
                 traffic, tsrc, stale, tmatch = pmc_traffic('r[0-9][0-9]_pmc_hbm_traffic*.json')
@@ -510,7 +510,7 @@ def main():
                         executed_gemm_tflop_per_step=fl_t / nprof / 1e12,
                         executed_note='algorithmic FLOPs of the GEMM launches as launched (the last block runs its out-proj / MLP on the class rows only, which '
                                       'algorithmic_tflop_per_step -- the survey\'s definition -- still counts in full); in the split-precision mode the '
-                                      'patch-embedding and QKV launches execute twice these FLOPs on the matrix cores (hi and lo halves) -- counted ONCE here, '
+                                      'patch-embedding launch and the Q / K columns of the QKV launches execute twice these FLOPs on the matrix cores (hi and lo halves) -- counted ONCE here, '
                                       'so `achieved` is algorithmic work over measured time',
                         mfma_tflop_per_step_issued=(fl_t / nprof + hilo_extra) / 1e12,
                         step_frac=flop_step * (a.steps / dt) / PEAK_TF,

@@ -133,6 +133,9 @@ def test_vit_through_the_wave_specialised_gemm(emu):
         K.check_vit(emu, 'cpu', check_fuse=False)
         cfg = dict(input_resolution=64, patch_size=16, width=256, layers=2, heads=4, output_dim=128)      # T = 17
         K.check_vit(emu, 'cpu', cfg, S=20, check_fuse=False)        # M = 340: two row tiles, the second ragged
+        # [r5] the split-precision QKV launch: long k-loops on the Q / K column tiles, half-length ones on the V column tiles, one walk
+        # (6 column tiles x 2 row panels: 8 long + 4 short tiles over the interpreter's workgroups)
+        K.check_vit(emu, 'cpu', cfg, S=20, check_fuse=False, hilo=True)
     finally:
         emu.cdll.aph_gemm_set_ws_min_tiles(prev)
 
