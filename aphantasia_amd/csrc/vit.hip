@@ -440,13 +440,14 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
         // large common offsets: through Q and K that error is amplified by the softmax, through V it enters the block linearly next to the f16
         // rounding V is stored with anyway (CPU model, tools/precision_attribution.py: single-step gradient error 5.2e-4 through Q / K, 1.8e-4
         // through V; on the GPU the single-step errors of the two forms are equal, profiles/r05_split_qk_only_ab.txt).  At full batch this is ONE
-        // launch of the wave-specialised kernel with two k-loop lengths (vit_gemm_ws.h); smaller batches take two launches with the same sums.
+        // launch of the wave-specialised kernel with two k-loop lengths (vit_gemm_ws.h).  Batches below that kernel's threshold are launch-bound,
+        // not MFMA-bound: they keep the plain launch over [hi | lo] on all 3 D columns (V a little more exact than it needs to be; a second
+        // launch per block would cost more than the shorter sums save: C1 726 -> 690 steps/s when it was tried).
         const EpiF16 eq{l.qkv, 3 * D, l.b_qkv};
         if (D % 128 == 0 && gemm_takes_ws(M, 2 * D, 3 * D, 2 * D)) {
           vtimed(v, 2.0 * M * 3 * D * D, st, [&] { launch_gemm_ws(v->h, 2 * D, l.w_qkv2, 2 * D, M, 3 * D, 2 * D, eq, st, nullptr, D, D); });
         } else {
-          vgemm(v, v->h, 2 * D, l.w_qkv2, 2 * D, M, 2 * D, 2 * D, eq, st, 2);
-          vgemm(v, v->h, 2 * D, l.w_qkv2 + (size_t)2 * D * 2 * D, 2 * D, M, D, D, EpiF16{l.qkv + 2 * D, 3 * D, l.b_qkv + 2 * D}, st);
+          vgemm(v, v->h, 2 * D, l.w_qkv2, 2 * D, M, 3 * D, 2 * D, eq, st, 2);      // (launch-bound sizes: one launch, the lo half on every column)
         }
       } else {
         vgemm(v, v->h, D, l.w_qkv, D, M, 3 * D, D, EpiF16{l.qkv, 3 * D, l.b_qkv}, st);
