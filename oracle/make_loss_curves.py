@@ -10,6 +10,7 @@ Configurations (seeded synthetic ViT-B/32 weights, `-tf none`, sim 'mix', Adam(l
     c2_s200_200  200 cuts, 200 steps         (BASELINE configs[1] verbatim)
     c2_s32       32 cuts, 200 steps          (BASELINE configs[1]'s step count)
     c2_s32_stress  32 cuts, 60 steps, `weights.stress_visual_weights` (LN gains 0.2-10, massive channels, peaky attention)
+    c2_s48_stress  the same at 48 cuts (a 4-rank shard of the headline: large enough for the full-batch GEMM kernel and its split-precision QKV form)
     c2_s190_fast 190 cuts, 60 steps, `-tf fast` (transforms.py:165-170 through oracle/augment_ref.apply_fast, the draws interleaved
                  per cut in the reference's order, utils.py:244-251): the configuration bench.py's headline `value` is measured on
 Both sides draw the crop tables with `R.draw_crop_table` after `seed_all(9)`; the parameters start from
@@ -37,6 +38,7 @@ CONFIGS = {
     'c2_s200_200': dict(h=720, w=1280, S=200, steps=200, weights='synthetic'),     # BASELINE configs[1] verbatim: samples=200, steps=200 (~45 min of CPU)
     'c2_s32': dict(h=720, w=1280, S=32, steps=200, weights='synthetic'),
     'c2_s32_stress': dict(h=720, w=1280, S=32, steps=60, weights='stress'),
+    'c2_s48_stress': dict(h=720, w=1280, S=48, steps=60, weights='stress'),        # [r5] 48 cuts = 2400 token rows: the QKV launch is on the wave-specialised kernel (the headline's arithmetic)
     'c2_s190_fast': dict(h=720, w=1280, S=190, steps=60, weights='synthetic', tf='fast'),   # --samples 200 -> int(200 * .95) cuts (clip_fft.py:169)
 }
 

@@ -180,6 +180,21 @@ def test_stress_weights_loss_curve_60steps_headline_mode_vs_oracle_fixture():
     assert rms < 0.05 and np.isfinite(got).all(), rms
 
 
+def test_stress_weights_loss_curve_48cuts_full_batch_kernels_vs_oracle_fixture():
+    """[r5] The stress-weight curve at 48 cuts (2400 token rows: a 4-rank shard of the headline): large enough for the QKV launch to run
+    on the wave-specialised kernel, i.e. in the split-precision form the 190-cut headline runs -- Q / K column tiles over [hi | lo], V column
+    tiles over the hi half -- which the 32-cut fixture (one plain launch over [hi | lo]) does not reach.  60 free-running steps against
+    tests/golden/loss_curve_c2_s48_stress.npz; the headline mode within north_star's 1e-3, f16 everywhere printed beside it (2e-3)."""
+    worst, first, rms, got = _curve('c2_s48_stress', precise=True)
+    print('stress weights, PRECISE mode, 48 cuts (full-batch QKV kernel), 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s), final block-mean RMS %.4f'
+          % (worst, first, rms))
+    w16, f16, r16, g16 = _curve('c2_s48_stress')
+    print('stress weights, f16 everywhere, 48 cuts, 60 free-running steps: max |d loss| %.2e (first step past 1e-3: %s)' % (w16, f16))
+    assert first is None and worst < 1e-3, (worst, first)
+    assert rms < 0.05 and np.isfinite(got).all(), rms
+    assert w16 < 2e-3 and np.isfinite(g16).all(), w16
+
+
 def test_c2_loss_curve_200cuts_50steps_precise_mode_vs_oracle_fixture():
     """plain synthetic weights, BASELINE's sample count, with the split-precision forward: at least as close as the default path"""
     worst, first, rms, _ = _curve('c2_s200', precise=True)
