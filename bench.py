@@ -62,7 +62,7 @@ def parse():
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-legs', action='store_true', help='skip the -tf none and with-save legs (N = 1 only has them)')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    p.add_argument('--f16', action='store_true', help='f16 operands on EVERY ViT GEMM (the opt-out of the split-precision forward): ~7 %% faster, '
+    p.add_argument('--f16', action='store_true', help='f16 operands on EVERY ViT GEMM (the opt-out of the split-precision forward): ~5 %% faster, '
                                                      'holds the stress-weight loss curve at 2e-3 instead of 1e-3')
     p.add_argument('--reps', type=int, default=3, help='repetitions of the timed block of --steps steps (value = the median block)')
     p.add_argument('--vit-path', default=None, help='measurement switch: comma list of name=int pairs handed to the library\'s test hooks '

@@ -77,7 +77,7 @@ def get_args(argv=None):
     parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
     parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
     parser.add_argument(       '--precise', action='store_true', help='(the default; kept for compatibility) split-precision ViT forward: hi + lo f16 operands on the patch-embedding and QKV GEMMs -- holds the loss curve within 1e-3 of the fp32 CPU reference on weights with large dynamic range')
-    parser.add_argument(       '--fast-f16', action='store_true', help='f16 operands on every ViT GEMM (what the reference runs CLIP at on a GPU): ~7 %% faster, loss curve within 2e-3 instead of 1e-3 on stress weights')
+    parser.add_argument(       '--fast-f16', action='store_true', help='f16 operands on every ViT GEMM (what the reference runs CLIP at on a GPU): ~5 %% faster, loss curve within 2e-3 instead of 1e-3 on stress weights')
     parser.add_argument(       '--aest-weights', dest='aest_weights', default=None, help="state dict of the LAION aesthetic head (sa_0_4_vit_b_32_linear.pth: "
                                "{'weight': [1,512], 'bias': [1]}); upstream downloads it (utils.py:402-413), there is no network here")
     parser.add_argument(       '--aest-weights2', dest='aest_weights2', default=None, help='the head of the --dualmod model (sa_0_4_vit_b_16_linear.pth)')
