@@ -136,6 +136,12 @@ def test_vit_through_the_wave_specialised_gemm(emu):
         # [r5] the split-precision QKV launch: long k-loops on the Q / K column tiles, half-length ones on the V column tiles, one walk
         # (6 column tiles x 2 row panels: 8 long + 4 short tiles over the interpreter's workgroups)
         K.check_vit(emu, 'cpu', cfg, S=20, check_fuse=False, hilo=True)
+        for pg in (2,):                                             # another tile order of the same walk (row panels per group)
+            prev_pg = emu.cdll.aph_gemm_set_ws_pgroup(pg)
+            try:
+                K.check_vit(emu, 'cpu', cfg, S=35, check_fuse=False, hilo=True)        # M = 595: three row panels, 12 long + 6 short tiles
+            finally:
+                emu.cdll.aph_gemm_set_ws_pgroup(prev_pg)
     finally:
         emu.cdll.aph_gemm_set_ws_min_tiles(prev)
 
