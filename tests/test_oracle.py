@@ -258,3 +258,26 @@ def test_depthwarp_oracle_vs_reference_golden(golden):
     assert torch.equal(D.resize(img, (28, 42)), t('resize_dn'))
     assert torch.equal(D.resize(dep[None], (70, 75)), t('resize_up'))
     assert torch.equal(D.depthwarp(img_t, img, D.toy_depth, 0.4, [0.2, -0.1], 0.6), t('depthwarp'))
+
+
+@pytest.mark.parametrize('name', ['c2_s32_stress', 'c2_s48_stress'])
+def test_loss_curve_fixture_first_step_reproduces(name):
+    """The committed free-running trajectories (tests/golden/loss_curve_*.npz, oracle/make_loss_curves.py) belong to THIS oracle: the
+    step-0 loss of a fresh ReferenceRun with the generator's seeds is the fixture's first entry (fp32 sums: thread-count noise only)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import clip_vit_ref, make_loss_curves as M, reference_path as R
+    c = M.CONFIGS[name]
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loss_curve_%s.npz' % name))
+    assert len(fx['loss']) == c['steps'] and ('%d cuts' % c['S']) in str(fx['meta'])
+    cfg, wts = M.weights_of(c['weights'])
+    M.seed_all(0)
+    p0 = R.fft_params_init([1, 3, c['h'], c['w']])
+    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
+    ref = R.ReferenceRun(c['h'], c['w'], lambda x: clip_vit_ref.encode_image(wts, x, cfg), [(target, 1.0)], params=p0)
+    M.seed_all(9)
+    table = R.draw_crop_table(c['S'], 224, c['h'], c['w'], 'uniform', 0.4)
+    with torch.no_grad():
+        got = float(ref.loss(table))
+    assert abs(got - float(fx['loss'][0])) < 5e-6, (got, float(fx['loss'][0]))
