@@ -124,3 +124,105 @@ def create(rank, world, device=None, lib=None, key=None):
         raise RuntimeError('comm.create: no way to hand the RCCL unique id to the other ranks (no torch.distributed group, no APH_RUN_ID '
                            'rendezvous key, no torchrun environment)')
     return Comm(rank, world, uid, lib)
+
+
+# ---- supervised fallback ladder for multi-rank launches --------------------------------------------------------------------------------
+# A rank that hangs inside a collective (or inside a graph capture that contains one) raises nothing: the only party that can end it is its
+# PARENT.  So every rank process of a multi-rank launch is a supervisor that runs the real work in a child of its own, one "rung" (mode of
+# operation) at a time, each rung under a wall budget; the supervisors of one launch agree through small files in a directory they share
+# (one node) on whether a rung succeeded on EVERY rank -- all or none -- and otherwise move to the next rung together.  bench.py uses it
+# so that `--gpus N` cannot end without its JSON line; it is independent of what the workers do.
+
+def _kill_group(p):
+    import signal
+    try:
+        os.killpg(p.pid, signal.SIGKILL)        # the worker was started in a session of its own: RCCL helper processes / threads go with it
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        p.wait(timeout=10)
+    except Exception:
+        pass
+
+
+def _die_with_parent():
+    """preexec of a worker: SIGKILL when its supervisor goes away (a launcher that kills the rank processes must not leave their workers behind)"""
+    try:
+        ctypes.CDLL(None).prctl(1, 9)           # PR_SET_PDEATHSIG, SIGKILL
+    except Exception:
+        pass
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def ladder(rank, world, rungs, make_cmd, sup_dir, budget_s=240.0, grace_s=30.0, log=None):
+    """Run `rungs` (a list of names) in order until one succeeds on every rank.
+
+    make_cmd(k, name, port) -> (argv, extra_env) of THIS rank's worker for rung k; its stdout goes to <sup_dir>/r<k>.rank<r>.out.
+    Every rank's supervisor must call this with the same rungs / budget and a `sup_dir` they all see (created if missing).
+    Returns (k or None, records, path of this rank's stdout file for rung k): records[k] = dict(rung, status per rank, seconds).
+    A worker counts as failed when it exits non-zero or is still running after `budget_s` (it is then killed with its process group)."""
+    import subprocess
+    os.makedirs(sup_dir, exist_ok=True)
+    log = log or (lambda s: None)
+    records = []
+
+    def wait_file(path, timeout):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            if os.path.isfile(path):
+                with open(path) as f:
+                    txt = f.read()
+                if txt.endswith('\n'):
+                    return txt.strip()
+            time.sleep(0.05)
+        return None
+
+    def publish(path, txt):
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'w') as f:
+            f.write(txt + '\n')
+        os.replace(tmp, path)
+
+    for k, name in enumerate(rungs):
+        t_rung = time.time()
+        port_file = os.path.join(sup_dir, 'r%d.port' % k)
+        if rank == 0:
+            publish(port_file, str(free_port()))
+        port = wait_file(port_file, budget_s + grace_s)
+        if port is None:
+            status = 'fail: no rendezvous port from rank 0'
+        else:
+            argv, extra = make_cmd(k, name, int(port))
+            env = dict(os.environ)
+            env.update(extra)
+            out_path = os.path.join(sup_dir, 'r%d.rank%d.out' % (k, rank))
+            with open(out_path, 'w') as out:
+                p = subprocess.Popen(argv, env=env, stdout=out, start_new_session=True, preexec_fn=_die_with_parent)
+                import signal
+                prev = signal.signal(signal.SIGTERM, lambda *_: (_kill_group(p), os._exit(143)))     # a terminated supervisor takes its worker along
+                try:
+                    rc = p.wait(timeout=budget_s)
+                    status = 'ok' if rc == 0 else 'fail: exit code %d' % rc
+                except subprocess.TimeoutExpired:
+                    _kill_group(p)
+                    status = 'fail: still running after %.0f s, killed' % budget_s
+                finally:
+                    signal.signal(signal.SIGTERM, prev)
+        publish(os.path.join(sup_dir, 'r%d.rank%d.status' % (k, rank)), status)
+        # all or none: a rung counts only if EVERY rank's worker finished (a missing status = that supervisor is gone)
+        deadline = t_rung + budget_s + grace_s
+        sts = []
+        for r in range(world):
+            s = wait_file(os.path.join(sup_dir, 'r%d.rank%d.status' % (k, r)), max(deadline - time.time(), 1.0))
+            sts.append(s if s is not None else 'fail: no status from its supervisor')
+        records.append(dict(rung=name, status=sts, seconds=round(time.time() - t_rung, 1)))
+        if all(s == 'ok' for s in sts):
+            return k, records, os.path.join(sup_dir, 'r%d.rank%d.out' % (k, rank))
+        log('rank %d: rung %d (%s) failed: %s' % (rank, k, name, '; '.join('rank %d %s' % (r, s) for r, s in enumerate(sts) if s != 'ok')))
+    return None, records, None

@@ -38,7 +38,7 @@ class Engine:
                  lr=0.05, optimizer='adam_custom', align='uniform', macro=0.4, transform=None,
                  size=None, rank=0, world=1, process_group=None, comm=None, param_kind='fft', decorrelate=True, lib=None, state=None, dwt=None, rng='bulk', use_graph=True,
                  rgb_priors=None, fixcontrast=False, sharp=0.0, expand=0.0, enforce=0.0, grad_f16=False, loss_scale=None, reduce_always=False, aest=None,
-                 precise=False):
+                 precise=False, graph_allreduce=None):
         """params: the leaf tensor ([1,3,h,w//2+1,2] spectrum for 'fft', [1,3,h,w] for 'pixel', the flat
         coefficient buffer for 'dwt' with dwt = its aphantasia_amd.dwt.DWTSynth);
         model: aphantasia_amd.clip.CLIPModel; targets: list of (embedding [1,D] tensor, coef) with
@@ -47,7 +47,11 @@ class Engine:
         distributions, ~0.1 ms/step); 'reference' = the reference's exact per-cut draw order on torch's / numpy's
         global generators (a seeded run then reproduces the reference's crop tables; costs milliseconds of Python).
         precise: the opt-in split-precision ViT forward (aph_vit_forward_hilo: the cuts and every block's first LayerNorm output as hi + lo
-        f16 pairs -- the two roundings that dominate the gradient error on weights with realistic dynamic range; ~8 % slower at C2)."""
+        f16 pairs -- the two roundings that dominate the gradient error on weights with realistic dynamic range; ~8 % slower at C2).
+        graph_allreduce: with world > 1 and a direct RCCL `comm`, capture the whole step INCLUDING its all-reduce into one hipGraph.  OPT-IN
+        (default: the environment's APH_MULTIRANK_GRAPH=1, else off -> multi-rank steps launch eagerly): until that path has executed on a
+        real multi-GPU node a hang inside the capture or its collectives would take a run down without an exception to catch (ADVICE r5);
+        bench.py tries it as the first rung of a parent-supervised ladder, which CAN end a hang."""
         self.params = params
         self.dev = params.device
         self.h, self.w = h, w
@@ -81,11 +85,14 @@ class Engine:
         # shard size).  Round 1 saw NaN gradients from replays next to eager work + device synchronizes; the cause turned out to
         # be the graph's MEMSET nodes (captured hipMemsetAsync), which this runtime mis-orders -- the step now zero-fills with
         # kernels (csrc/aph_device.h zero_fill_async; repro: tools/exp/frame_debug3.py on the commit before).
-        # Multi-rank: with a direct RCCL communicator the whole step INCLUDING the all-reduce and Adam is one graph too (a shard's step
-        # is ~230 launches of 5-15 us: eager launches there are host-bound) -- behind a ONE-TIME self-check at capture (_capture: the
-        # replay must reproduce an eager step bit for bit on every rank, else the engine stays eager and says so).  Through
+        # Multi-rank: with a direct RCCL communicator AND graph_allreduce the whole step INCLUDING the all-reduce and Adam is one graph too
+        # (a shard's step is ~230 launches of 5-15 us: eager launches there are host-bound) -- behind a ONE-TIME self-check at capture
+        # (_capture: the replay must reproduce an eager step bit for bit on every rank, else the engine stays eager and says so).  Through
         # torch.distributed (the gloo / CPU test path) the collective cannot be a graph node: eager.
-        if world > 1 and comm is None:
+        if graph_allreduce is None:
+            graph_allreduce = os.environ.get('APH_MULTIRANK_GRAPH', '0') == '1'
+        self.graph_allreduce = bool(graph_allreduce)
+        if world > 1 and (comm is None or not self.graph_allreduce):
             use_graph = False
         self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets

@@ -142,40 +142,37 @@ def slice_imgs(imgs, count, size=224, transform=None, align='uniform', macro=0.,
     return sliced
 
 
-def tile_pad(xt, padding, symm=False):
-    """utils.py:152-176 (index gather; host-built indices)"""
-    h, w = xt.shape[-2:]
-    left, right, top, bottom = padding
+def _wrapped_index(n, before, after, mirror, device):
+    """source index of every padded position -before .. n + after - 1: periodic (i mod n), or mirrored with the edge sample repeated"""
+    i = torch.arange(-before, n + after, device=device)
+    if not mirror:
+        return i.remainder(n)
+    m = i.remainder(2 * n)
+    return torch.where(m < n, m, 2 * n - 1 - m)
 
-    def tile(x, minx, maxx):
-        rng = maxx - minx
-        if symm is True:
-            double_rng = 2 * rng
-            mod = np.fmod(x - minx, double_rng)
-            normed_mod = np.where(mod < 0, mod + double_rng, mod)
-            out = np.where(normed_mod >= rng, double_rng - normed_mod, normed_mod) + minx
-        else:
-            out = np.remainder(x - minx, rng) + minx
-        return np.array(out, dtype=x.dtype)
-    x_pad = tile(np.arange(-left, w + right), -0.5, w - 0.5)
-    y_pad = tile(np.arange(-top, h + bottom), -0.5, h - 0.5)
-    xx, yy = np.meshgrid(x_pad, y_pad)
-    return xt[..., torch.from_numpy(yy).to(xt.device), torch.from_numpy(xx).to(xt.device)]
+
+def tile_pad(xt, padding, symm=False):
+    """Periodic (or, with symm, mirrored) extension of the last two axes by padding = (left, right, top, bottom) -- the result upstream's
+    helper of the same name produces (utils.py:152-176), built here as two 1-D index vectors and two index_select gathers.  The fused
+    sampler never materialises this image: it wraps its source coordinates instead (csrc/sampler.hip)."""
+    left, right, top, bottom = padding
+    h, w = xt.shape[-2:]
+    rows = _wrapped_index(h, top, bottom, symm is True, xt.device)
+    cols = _wrapped_index(w, left, right, symm is True, xt.device)
+    return xt.index_select(-2, rows).index_select(-1, cols)
 
 
 def pad_up_to(x, size, type='centr'):
-    """utils.py:178-190"""
-    sh = x.shape[2:][::-1]
-    if list(x.shape[2:]) == list(size):
+    """x [N,C,h,w] extended to size = (H, W): the extra rows / columns split evenly around the image ('centr') or all appended after it
+    ('side'), periodic unless the type says 'symm' (utils.py:178-190)"""
+    (H, W), (h, w) = size, x.shape[2:]
+    if (h, w) == (H, W):
         return x
-    padding = []
-    for i, s in enumerate(size[::-1]):
-        if 'side' in type.lower():
-            padding = padding + [0, s - sh[i]]
-        else:
-            p0 = (s - sh[i]) // 2
-            padding = padding + [p0, s - sh[i] - p0]
-    return tile_pad(x, padding, symm=('symm' in type.lower()))
+    kind = type.lower()
+
+    def split(extra):
+        return (0, extra) if 'side' in kind else (extra // 2, extra - extra // 2)
+    return tile_pad(x, split(W - w) + split(H - h), symm='symm' in kind)
 
 
 # ----------------------------------------------------------------------------- loss

@@ -99,7 +99,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(w, h, model_name, samples, seed=0, budget_s=30.0):
+def cpu_baseline(w, h, model_name, samples, seed=0, budget_s=30.0, tf='none'):
     """The oracle's train(i) (oracle/reference_path.py: fp32 torch-CPU restatement of the reference's own path, -tf none) timed on
     the host cores.  (1) thread sweep: one warm 16-cut + one timed 64-cut step at each of {16, 32, 64, 128} threads (torch's default -- every hardware
     thread of the box -- is catastrophically oversubscribed on this workload: 17.9 s per step at 128 threads in round 2, 5.6 s at 16) ; (2) the two best counts are
@@ -108,7 +108,7 @@ def cpu_baseline(w, h, model_name, samples, seed=0, budget_s=30.0):
     reference's DEFAULT form, where the CLIP weights require grad and their gradients are computed and thrown away (BASELINE.md
     section 4) -- reported next to the input-gradient-only number, never instead of it."""
     from oracle import reference_path as R
-    from oracle import clip_vit_ref
+    from oracle import augment_ref, clip_vit_ref
     from aphantasia_amd.weights import synthetic_visual_weights, visual_config
     cfg = visual_config(model_name)
     wts = synthetic_visual_weights(cfg, 1)
@@ -118,10 +118,53 @@ def cpu_baseline(w, h, model_name, samples, seed=0, budget_s=30.0):
     t_before = torch.get_num_threads()
     small = min(16, samples)
 
+    # kind "reference" when the reference tree is importable (the build container; never the GPU box): train(i) assembled from the
+    # reference's OWN fft_image / to_valid_rgb / slice_imgs / normalize / sim_func (oracle/shim.py imports them in place) + torch.optim.Adam
+    # as at clip_fft.py:108-115,235-295 -- only CLIP's encode_image is the restatement (openai/CLIP is a third-party package that is not
+    # in the reference tree).  Otherwise kind "port": the oracle's restatement of the same functions.
+    ref = None
+    try:
+        from oracle import shim
+        if shim.available():
+            ref = shim.load_reference()
+    except Exception as e:
+        print('bench.py: the reference tree is present but could not be imported (%r): cpu_baseline falls back to the port' % (e,), file=sys.stderr)
+        ref = None
+
+    class RefRun:
+        """the reference's own functions, called as clip_fft.py:91-101,108-115,235-295 calls them (-tf none)"""
+        def __init__(self, weights):
+            self.params, image_f, _ = ref.fft_image([1, 3, h, w], 0.01, 1.5)
+            self.image_f = ref.to_valid_rgb(image_f, colors=1.8)
+            self.opt = torch.optim.Adam(self.params, 0.05, betas=(.0, .999))
+            self.enc = lambda x: clip_vit_ref.encode_image(weights, x, cfg)
+            self.norm = ref.normalize()
+
+        def step(self, n):
+            img = self.image_f(None)
+            cuts = ref.slice_imgs([img], n, 224, self.norm, 'uniform', 0.4)[0]
+            loss = -1.0 * ref.sim_func(target, self.enc(cuts), 'mix')
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            return float(loss.detach())
+
     def fresh(weights):
+        if ref is not None:
+            return RefRun(weights)
         return R.ReferenceRun(h, w, lambda x: clip_vit_ref.encode_image(weights, x, cfg), [(target, 1.0)])
 
     def one(run, n):
+        if ref is not None:
+            t0 = time.perf_counter()
+            run.step(n)
+            return time.perf_counter() - t0
+        if tf == 'fast':       # the same augment chain as `value` (transforms.py:165-170 through the oracle's restated torchvision ops), drawn per cut in the reference's order
+            augs = []
+            table = R.draw_crop_table(n, 224, h, w, 'uniform', 0.4, per_cut_hook=lambda _c: augs.append(augment_ref.draw_fast_params(224)))
+            t0 = time.perf_counter()
+            run.step(table, lambda k, cut: augment_ref.apply_fast(cut, augs[k], R.normalize))
+            return time.perf_counter() - t0
         table = R.draw_crop_table(n, 224, h, w, 'uniform', 0.4)
         t0 = time.perf_counter()
         run.step(table)
@@ -157,10 +200,15 @@ def cpu_baseline(w, h, model_name, samples, seed=0, budget_s=30.0):
     one(run_wg, small)
     t_wg = one(run_wg, samples)
     torch.set_num_threads(t_before)
-    return dict(value=1.0 / med, unit='steps/s', cores=best, kind='port', cpu=cpu_model(), host_threads_available=nproc,
-                sample='%d timed full train(i) steps (median) at %dx%d, %d cuts, %s, fp32 torch-CPU oracle (-tf none), %d threads (the better of the two best '
+    tf_used = 'none' if ref is not None else tf
+    return dict(value=1.0 / med, unit='steps/s', cores=best, kind='reference' if ref is not None else 'port', cpu=cpu_model(), host_threads_available=nproc,
+                transform=tf_used,
+                sample='%d timed full train(i) steps (median) at %dx%d, %d cuts, %s, -tf %s%s, fp32 torch-CPU %s, %d threads (the better of the two best '
                        'counts of a %d-cut sweep over {16, 32, 64, 128} threads, each timed at the full size), after a %d-cut warm-up step'
-                       % (len(times), w, h, samples, model_name, best, sweep_cuts, small),
+                       % (len(times), w, h, samples, model_name, tf_used,
+                          '' if tf_used == tf else ' (`value` runs -tf %s: the reference\'s transforms_fast needs torchvision, which is not in this image)' % tf,
+                          "reference functions (aphantasia/image.py, utils.py, transforms.py imported in place; CLIP encode_image = the oracle's restatement)" if ref is not None
+                          else 'oracle restatement of the reference path (the reference tree is not on this machine)', best, sweep_cuts, small),
                 seconds=med, seconds_all=times, thread_sweep={'cuts': sweep_cuts, 'seconds_per_step': {str(k): v for k, v in sweep.items()}},
                 full_size_seconds_by_threads={str(k): v for k, v in full.items()},
                 reference_default=dict(value=1.0 / t_wg, seconds=t_wg, note='CLIP weights require grad: their gradients are computed and discarded, as '
@@ -298,10 +346,76 @@ def pmc_traffic(tag_glob):
     return best if best else (None, None, None, None)
 
 
-def _spawned_rank(local_rank, world, port):
-    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY='0')
-    main()
+RUNGS = ('graph+rccl', 'eager+rccl', 'eager+torch')
+RUNG_NOTE = {'graph+rccl': 'whole step incl. ncclAllReduce in ONE hipGraph, RCCL called directly (aph_allreduce_f32); control plane (barriers, timing MAX) on a gloo group',
+             'eager+rccl': 'eager launches, RCCL called directly (aph_allreduce_f32); control plane on a gloo group',
+             'eager+torch': 'eager launches, all-reduce through torch.distributed (nccl backend = RCCL)'}
+
+
+def launch_supervisors(a):
+    """plain `python bench.py --gpus N`: start the N rank processes here, exactly as torchrun would (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment); each of them then supervises its own worker (supervise())"""
+    import shutil
+    import subprocess
+    import tempfile
+    from aphantasia_amd.comm import free_port
+    sup = tempfile.mkdtemp(prefix='aph_bench_sup_')
+    port = free_port()
+    procs = []
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       APH_BENCH_SUP_DIR=sup, HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = max(p.wait() for p in procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(sup, ignore_errors=True)
+    if rc:
+        raise SystemExit(rc)
+
+
+def supervise(a, rank, world):
+    """A rank process of a multi-rank launch (torchrun's or launch_supervisors'): it does no GPU work itself.  It runs the measurement in
+    a WORKER child, one rung of RUNGS at a time under a wall budget (APH_BENCH_RUNG_BUDGET seconds, default 240), and agrees with the other
+    ranks' supervisors through files on whether the rung succeeded everywhere (aphantasia_amd.comm.ladder).  A worker that hangs in a
+    capture or a collective is killed by its supervisor and the next rung starts on every rank; rank 0 prints the successful rung's JSON
+    line with `config.multi_rank_mode` and the ladder's record -- or, if every rung failed, a line that says so.  (the
+    first N > 1 run must not be able to end without a line.)"""
+    import tempfile
+    from aphantasia_amd.comm import ladder
+    sup = os.environ.get('APH_BENCH_SUP_DIR') or os.path.join(tempfile.gettempdir(), 'aph_bench_sup_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
+    budget = float(os.environ.get('APH_BENCH_RUNG_BUDGET', '240'))
+    rungs = [r for r in os.environ.get('APH_BENCH_RUNGS', ','.join(RUNGS)).split(',') if r]
+    for r in rungs:
+        if r not in RUNGS:
+            raise SystemExit('APH_BENCH_RUNGS: unknown rung %r (known: %s)' % (r, ', '.join(RUNGS)))
+    os.environ.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # the workers rendezvous on a port of their own (rank 0's worker hosts the store)
+
+    def make_cmd(k, name, port):
+        return ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                dict(APH_BENCH_WORKER='1', APH_BENCH_RUNG=name, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), APH_BENCH_RUNG_BUDGET=str(budget)))
+    k, records, out_path = ladder(rank, world, rungs, make_cmd, sup, budget_s=budget, grace_s=30.0,
+                                  log=lambda m: print('bench.py supervisor ' + m, file=sys.stderr, flush=True))
+    if rank == 0:
+        line = None
+        if k is not None:
+            with open(out_path) as f:
+                cand = [l for l in f.read().splitlines() if l.startswith('{')]
+            if cand:
+                line = json.loads(cand[-1])
+                line['config']['multi_rank_mode'] = rungs[k]
+                line['config']['multi_rank_mode_note'] = RUNG_NOTE[rungs[k]]
+                line['config']['multi_rank_ladder'] = records
+        if line is None:
+            line = {'metric': 'optimization steps/sec', 'value': None, 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                    'ms_per_step': None, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'data': 'synthetic',
+                    'error': 'every rung of the multi-rank ladder failed: no measurement', 'config': {'multi_rank_mode': None, 'multi_rank_ladder': records}}
+        print(json.dumps(line), flush=True)
+    if k is None:
+        raise SystemExit(1)
 
 
 def main():
@@ -312,26 +426,24 @@ def main():
         have = torch.cuda.device_count()
         if have < a.gpus and os.environ.get('APH_BENCH_BACKEND', 'nccl') == 'nccl':
             raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to print a line that is not an N-GPU measurement' % (a.gpus, have))
-        from aphantasia_amd.comm import spawn_ranks
-        spawn_ranks(_spawned_rank, (a.gpus, 20000 + int.from_bytes(os.urandom(2), 'little') % 20000), a.gpus)
+        launch_supervisors(a)
         return
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    # watchdog (rank processes only, never the spawning parent): dump every thread's Python stack and exit if the TIMED multi-rank section is
-    # still going after N seconds (APH_BENCH_WATCHDOG=N, default 900 for world > 1; 0 = off) -- a rank stuck in a collective should fail
-    # loudly with a stack, not sit in the launcher's timeout.  It is cancelled once the timed section and the rank checks are through, so a
-    # slow but healthy run (legs, CPU baseline) is never killed by it.
-    wd_s = os.environ.get('APH_BENCH_WATCHDOG', '900' if world > 1 else '0')
-    try:
-        wd = max(int(wd_s), 0)
-    except ValueError:
-        raise SystemExit('APH_BENCH_WATCHDOG=%r is not a number of seconds' % wd_s)
-    if wd > 0:
-        import faulthandler
-        faulthandler.dump_traceback_later(wd, exit=True)
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if world > 1 and os.environ.get('APH_BENCH_WORKER') != '1':
+        supervise(a, rank, world)
+        return
+    rung = os.environ.get('APH_BENCH_RUNG', RUNGS[0]) if world > 1 else None
+    # in-worker watchdog: shortly before the supervisor's budget runs out, dump every thread's Python stack to stderr (the supervisor then
+    # kills the worker): a rank stuck in a collective leaves a stack behind, not just a timeout.  Cancelled after the timed section.
+    wd = 0
+    if world > 1:
+        wd = max(int(float(os.environ.get('APH_BENCH_RUNG_BUDGET', '240'))) - 15, 5)
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=False)
     # debugging aid for single-GPU boxes: APH_BENCH_BACKEND=gloo puts every rank on cuda:0 and reduces through the host
     backend = os.environ.get('APH_BENCH_BACKEND', 'nccl')
     if backend != 'nccl':
@@ -339,13 +451,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     pg = None
+    ctl = dev                     # device of the control-plane tensors (timing MAX, parameter hashes)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
+        # ONE RCCL communicator per GPU: with the direct communicator (rungs 1 / 2) the control plane is a gloo group; only the
+        # torch.distributed rung holds an nccl group (and then no direct communicator)
+        if backend == 'nccl' and rung == 'eager+torch':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            ctl = torch.device('cpu')
 
     from aphantasia_amd import clip as aclip, transforms
     from aphantasia_amd.engine import Engine
@@ -362,12 +478,14 @@ def main():
     # 128-byte unique id and does the barriers / the MAX over ranks of the timing contract.  APH_COMM=torch: all-reduce through
     # torch.distributed instead (cross-check)
     comm = None
-    if world > 1 and backend == 'nccl' and os.environ.get('APH_COMM', 'rccl') == 'rccl':
+    if world > 1 and backend == 'nccl' and rung in ('graph+rccl', 'eager+rccl'):
         from aphantasia_amd import comm as acomm
-        try:
-            comm = acomm.create(rank, world)
-        except Exception as e:                 # keep the run alive on the torch.distributed path, loudly
-            print('bench.py rank %d: direct RCCL communicator failed (%s); falling back to torch.distributed.all_reduce' % (rank, e), file=sys.stderr, flush=True)
+        comm = acomm.create(rank, world)      # (a failure here fails this rung on every rank: the supervisors move on to the next one)
+    use_graph = not a.no_graph and rung in (None, 'graph+rccl')
+    if world > 1 and os.environ.get('APH_BENCH_INJECT_HANG') == rung and rank == world - 1:
+        # TEST-ONLY hang injection (tools/gpu.sh mr2hang, tests of the ladder): the last rank never reaches the step's collective
+        print('bench.py rank %d: APH_BENCH_INJECT_HANG=%s -- sleeping forever (test)' % (rank, rung), file=sys.stderr, flush=True)
+        time.sleep(1e6)
     w, h = [int(s) for s in cfg['size'].split('-')]
     dualmod = cfg.get('dualmod')
     S = derate(cfg['samples'], cfg['model'], cfg['transform'], dualmod)
@@ -387,7 +505,7 @@ def main():
         trf = transforms.transforms_fast if transform_name == 'fast' else transforms.normalize()
         torch.manual_seed(0)
         np.random.seed(0)
-        kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, comm=comm, use_graph=not a.no_graph)
+        kw = dict(sim=sim, transform=trf, macro=cfg['macro'], rank=rank, world=world, process_group=pg, comm=comm, use_graph=use_graph, graph_allreduce=(rung == 'graph+rccl') or None)
         for k in ('align', 'colors', 'lr'):
             if k in cfg:
                 kw[k] = cfg[k]
@@ -441,7 +559,7 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=ctl, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
         return dt
@@ -459,7 +577,7 @@ def main():
         import torch.distributed as dist
         ranks_seen = comm.ranks_seen() if comm is not None else dist.get_world_size()
         bits = eng.params.detach().reshape(-1).view(torch.int32).to(torch.int64)
-        hsh = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+        hsh = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()]).to(ctl)
         hs = [torch.zeros_like(hsh) for _ in range(world)]
         dist.all_gather(hs, hsh)
         params_identical = all(bool(torch.equal(hs[0], x)) for x in hs[1:])
@@ -593,7 +711,7 @@ def main():
             np.random.seed(0)
             _, image_f, _ = dwt_image([1, 3, h4, w4], c4['dwt'], 0.3, 1.8, None)
             e4 = Engine(image_f.flat, h4, w4, m4, S4, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=c4['macro'],
-                        param_kind='dwt', dwt=image_f.synth, use_graph=not a.no_graph)
+                        param_kind='dwt', dwt=image_f.synth, use_graph=use_graph)
             n4 = min(a.steps, 10)
             dt4 = timed(e4, None, n4, 3)
             legs['c4'] = dict(value=n4 / dt4, unit='steps/s', ms_per_step=1e3 * dt4 / n4, steps=n4, samples_effective=S4, skipped_steps=int(e4.guard[0]),
@@ -615,7 +733,7 @@ def main():
         if cfg.get('dwt') or dualmod is not None or cfg.get('illustrip'):
             cpu = None          # the oracle leg is defined for the FFT single-model step; C3 / C4 lines report the GPU side only
         else:
-            cpu = cpu_baseline(w, h, cfg['model'], S)
+            cpu = cpu_baseline(w, h, cfg['model'], S, tf=cfg['transform'])
 
     if rank == 0:
         steps_per_s = a.steps / dt

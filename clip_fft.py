@@ -86,6 +86,9 @@ def get_args(argv=None):
                                "'bulk' = vectorised draws from a numpy Generator (same distributions, a different stream, ~10x less host time). "
                                "Default: reference when --seed is given, else bulk")
     parser.add_argument(       '--ranks',   default=1, type=int, help='GPUs of this node to shard the cuts over (launch with torchrun, or let this flag spawn the ranks)')
+    parser.add_argument(       '--graph-allreduce', action='store_true', help='with --ranks N: capture the whole step INCLUDING its RCCL all-reduce into one hipGraph '
+                               '(opt-in: multi-rank steps launch eagerly by default; same as APH_MULTIRANK_GRAPH=1)')
+    parser.add_argument(       '--no-graph', action='store_true', help='eager launches instead of hipGraph replay (debugging)')
     a = parser.parse_args(argv)
 
     if a.size is not None: a.size = [int(s) for s in a.size.split('-')][::-1]        # clip_fft.py:80
@@ -336,13 +339,13 @@ def main(argv=None):
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                  optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                 rank=rank, world=world, comm=comm, aest=aest1, precise=not a.fast_f16, **pk)
+                 rank=rank, world=world, comm=comm, aest=aest1, precise=not a.fast_f16, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                       optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                      rank=rank, world=world, comm=comm, aest=aest2, precise=not a.fast_f16, **pk)
+                      rank=rank, world=world, comm=comm, aest=aest2, precise=not a.fast_f16, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp

@@ -75,6 +75,8 @@ def get_args(argv=None):
     p.add_argument('--no_save', action='store_true')
     p.add_argument('--rng', default=None, choices=['bulk', 'reference'])
     p.add_argument('--ranks', default=1, type=int, help='GPUs of this node to shard the cuts over (launch with torchrun, or let this flag spawn the ranks)')
+    p.add_argument('--graph-allreduce', action='store_true', help='with --ranks N: the step incl. its RCCL all-reduce as one hipGraph (opt-in; APH_MULTIRANK_GRAPH=1)')
+    p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay (debugging)')
     a = p.parse_args(argv)
     a.size = [int(s) for s in a.size.split('-')][::-1]                    # illustrip.py:90-91
     if len(a.size) == 1: a.size = a.size * 2
@@ -172,7 +174,7 @@ def main(argv=None):
         leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).cuda().contiguous()
         pk = dict(param_kind='fft', decay=1.0)                                                  # fft_image default decay_power (illustrip.py:409)
     kw = dict(sim=a.sim, colors=a.colors, lr=a.lrate, optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trf, sharp=a.sharp,
-              expand=a.expand, enforce=a.enforce, rng=a.rng, rank=rank, world=world, comm=comm, **pk)
+              expand=a.expand, enforce=a.enforce, rng=a.rng, rank=rank, world=world, comm=comm, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
     eng = Engine(leaf, h, w, model, S, targets_for(model), **kw)
     eng2 = Engine(leaf, h, w, model2, S, targets_for(model2), state=eng.state(), **kw) if model2 is not None else None
     depth_fn = None

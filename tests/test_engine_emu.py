@@ -72,7 +72,7 @@ def _emu_lib():
     return _ffi.Library(build_emu.build())
 
 
-def _make_engine(lib, rank=0, world=1, pg=None, sim='mix', optimizer='adam_custom'):
+def _make_engine(lib, rank=0, world=1, pg=None, sim='mix', optimizer='adam_custom', S=S):
     from aphantasia_amd.clip import CLIPModel
     w = synthetic_visual_weights(TINY, 3)
     model = CLIPModel('tiny', TINY, w, None, max_batch=S, lib=lib)
@@ -100,13 +100,13 @@ def test_engine_free_running_vs_oracle():
     assert (eng.synthesize(1.1) - img).pow(2).mean().sqrt().item() < 2e-2
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cuts=S):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     lib = _emu_lib()
-    eng, w, target = _make_engine(lib, rank, world)
+    eng, w, target = _make_engine(lib, rank, world, S=cuts)
     seed_all(123)
     losses = []
     for _ in range(2):
@@ -117,11 +117,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_engine_two_ranks_gloo():
+@pytest.mark.parametrize('world,cuts', [(2, 5), (3, 7)])
+def test_engine_ranks_gloo(world, cuts):
+    """SURVEY section 8(e) acceptance at small scale: the cuts split over `world` ranks (shards of unequal size: 3 + 2, 3 + 2 + 2), one
+    all-reduce of the partial spectrum gradient per step -> every rank holds bit-identical parameters, the summed partial losses equal
+    the single-rank loss, and the run equals the single-rank run up to summation order"""
     import torch.multiprocessing as mp
     _emu_lib()                                 # build once before forking workers
     lib = _emu_lib()
-    eng, _, _ = _make_engine(lib)
+    eng, _, _ = _make_engine(lib, S=cuts)
     seed_all(123)
     want_losses = []
     for _ in range(2):
@@ -129,14 +133,17 @@ def test_engine_two_ranks_gloo():
         want_losses.append(eng.global_loss())
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    from aphantasia_amd.comm import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cuts)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
-    assert np.array_equal(res[0][1], res[1][1])                      # ranks stay bit-identical
+    for r in range(1, world):
+        assert np.array_equal(res[0][1], res[r][1])                  # ranks stay bit-identical
+        assert res[0][2] == res[r][2]                                # and report the same global loss
     # == the single-rank run up to fp32 summation order of the partial gradients; Adam(beta1=0) turns
     # rounding-level differences of near-zero gradient entries into visible (but tiny) parameter differences
     d = np.abs(res[0][1] - eng.params.numpy())

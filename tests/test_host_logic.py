@@ -261,3 +261,122 @@ def test_bench_traffic_summary_matching(tmp_path, monkeypatch):
     assert real['gemm_src_sha256'] == bench.gemm_src_sha()
     real4 = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r04_c4_pmc_hbm_traffic.json')))
     assert real4['irdwt_fwd_bytes_per_pass'] > 2.6e8
+
+
+def _write_counters(d, counter, launches):
+    """a minimal rocprofv3 counter_collection.csv: `launches` = [(kernel name, value), ...]"""
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, 'x_counter_collection.csv'), 'w') as f:
+        f.write('Kernel_Name,Counter_Name,Counter_Value\n')
+        for k, v in launches:
+            f.write('"%s",%s,%f\n' % (k, counter, v))
+
+
+def test_pmc_traffic_derives_the_step_count_from_the_trace(tmp_path, monkeypatch):
+    """tools/pmc_traffic.py: the number of optimisation steps of the profiled run comes from the adam_kernel launches of the trace, never
+    from the command line (round 5 published an irDWT traffic 2.2x too high through a stale argv step count); passes of different length,
+    traces without an Adam launch and family counts that do not divide by the step count are refused and nothing is written"""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'pmc_traffic.py')
+    gemm, adam, lvl, adj = 'void aph::gemm_ws_kernel<A>(x)', 'void aph::adam_kernel<0>(y)', 'void aph::idwt_level_kernel<3>(z)', 'void aph::idwt_level_adjoint_kernel<3>(z)'
+    steps = 11
+
+    def trace(n_steps, n_gemm=4, n_lvl=5):
+        rows = []
+        for _ in range(n_steps):
+            rows += [(gemm, 1000.0)] * n_gemm + [(lvl, 500.0)] * n_lvl + [(adj, 250.0)] * n_lvl + [(adam, 10.0)]
+        return rows
+    fd, wd, out = str(tmp_path / 'f'), str(tmp_path / 'w'), str(tmp_path / 'out')
+    _write_counters(fd, 'FETCH_SIZE', trace(steps))
+    _write_counters(wd, 'WRITE_SIZE', trace(steps))
+    env = dict(os.environ, APH_PMC_OUT=out)
+    r = subprocess.run([sys.executable, tool, fd, wd, 'rXX_c4', 'note'], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    j = json.load(open(os.path.join(out, 'rXX_c4_pmc_hbm_traffic.json')))
+    assert j['steps_in_run'] == steps and j['gemm_launches_per_step'] == 4
+    assert abs(j['traffic_bytes_per_launch'] - (2 * 1000 + 1000) * 1024) < 1
+    assert abs(j['irdwt_fwd_bytes_per_pass'] - 5 * (2 * 500 + 500) * 1024) < 1 and abs(j['irdwt_bwd_bytes_per_pass'] - 5 * (2 * 250 + 250) * 1024) < 1
+    # the old calling convention (a step count as the third argument) is refused loudly
+    r = subprocess.run([sys.executable, tool, fd, wd, '5', 'rYY'], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'derived' in (r.stderr + r.stdout) and not os.path.exists(os.path.join(out, 'rYY_pmc_hbm_traffic.json'))
+    # passes of different length
+    _write_counters(wd, 'WRITE_SIZE', trace(steps - 1))
+    r = subprocess.run([sys.executable, tool, fd, wd, 'rZZ'], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'different step counts' in (r.stderr + r.stdout) and not os.path.exists(os.path.join(out, 'rZZ_pmc_hbm_traffic.json'))
+    # a truncated trace: GEMM launches that do not divide by the steps
+    _write_counters(fd, 'FETCH_SIZE', trace(steps) + [(gemm, 1.0)])
+    _write_counters(wd, 'WRITE_SIZE', trace(steps) + [(gemm, 1.0)])
+    r = subprocess.run([sys.executable, tool, fd, wd, 'rZZ'], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'do not divide' in (r.stderr + r.stdout) and not os.path.exists(os.path.join(out, 'rZZ_pmc_hbm_traffic.json'))
+    # no Adam launch at all
+    _write_counters(fd, 'FETCH_SIZE', [(gemm, 1.0)])
+    r = subprocess.run([sys.executable, tool, fd, wd, 'rZZ'], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'adam_kernel' in (r.stderr + r.stdout)
+
+
+_LADDER_SUP = '''
+import sys, json
+sys.path.insert(0, %r)
+from aphantasia_amd.comm import ladder
+rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+def mk(k, name, port):
+    code = {'hang': "import time\\nif %%d == 1: time.sleep(1000)\\nprint('hang-rung')" %% rank,
+            'crash': "import sys\\nsys.exit(3 if %%d == 0 else 0)" %% rank,
+            'good': "print('{\\"port\\": %%d, \\"rank\\": %%d}')" %% (port, rank)}[name]
+    return [sys.executable, '-c', code], {'X_RUNG': name}
+k, rec, out = ladder(rank, world, sys.argv[4].split(','), mk, d, budget_s=3.0, grace_s=4.0)
+print(json.dumps(dict(k=k, rec=rec, out=open(out).read() if out else None)))
+'''
+
+
+@pytest.mark.parametrize('rungs,want_k', [('hang,crash,good', 2), ('hang,crash', None)])
+def test_multi_rank_ladder_survives_hangs_and_crashes(tmp_path, rungs, want_k):
+    """aphantasia_amd.comm.ladder (what bench.py --gpus N runs its ranks under): a worker that HANGS on one rank is killed at the rung's
+    budget, a worker that exits non-zero on one rank fails the rung on every rank (all or none), and every supervisor arrives at the same
+    rung -- or, when every rung fails, at None with the full record (bench.py then still prints a line)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ps = [subprocess.Popen([sys.executable, '-c', _LADDER_SUP % root, str(r), '2', str(tmp_path / 'sup'), rungs], stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in ps]
+    assert outs[0]['k'] == outs[1]['k'] == want_k
+    strip = lambda rec: [(r['rung'], r['status']) for r in rec]
+    assert strip(outs[0]['rec']) == strip(outs[1]['rec'])
+    rec = outs[0]['rec']
+    assert rec[0]['rung'] == 'hang' and rec[0]['status'][0] == 'ok' and 'killed' in rec[0]['status'][1]
+    assert rec[1]['rung'] == 'crash' and 'exit code 3' in rec[1]['status'][0] and rec[1]['status'][1] == 'ok'
+    if want_k is not None:
+        assert rec[2]['status'] == ['ok', 'ok']
+        a, b = json.loads(outs[0]['out']), json.loads(outs[1]['out'])
+        assert a['port'] == b['port'] and (a['rank'], b['rank']) == (0, 1)         # both workers of a rung get rank 0's port
+    else:
+        assert outs[0]['out'] is None
+
+
+def test_pad_up_to_and_tile_pad_semantics():
+    """aphantasia_amd.utils.pad_up_to / tile_pad (the API-compatibility helpers; the fused sampler wraps coordinates instead): periodic
+    'centr' extension equals the oracle's restatement of utils.py:152-190 (itself pinned to the reference through the overscan / overmax
+    goldens), 'side' appends after the image, 'symm' mirrors with the edge sample repeated, the gather is differentiable"""
+    from aphantasia_amd import utils as U
+    from oracle import reference_path as R
+    torch.manual_seed(0)
+    for (h, w, H, W) in [(5, 7, 9, 12), (4, 4, 4, 9), (6, 3, 15, 3), (3, 5, 20, 31), (48, 80, 72, 120)]:
+        x = torch.randn(2, 3, h, w)
+        assert torch.equal(U.pad_up_to(x, (H, W)), R.pad_up_to(x, (H, W)))
+        side = U.pad_up_to(x, (H, W), 'side')
+        assert torch.equal(side[..., :h, :w], x)
+        assert torch.equal(side, torch.cat([torch.cat([x] * (H // h + 1), 2)[..., :H, :]] * (W // w + 1), 3)[..., :W])
+    x = torch.arange(12.).reshape(1, 1, 3, 4)
+    m = U.tile_pad(x, (2, 5, 1, 4), symm=True)
+    assert m.shape == (1, 1, 8, 11)
+    assert m[0, 0, 1].tolist() == [1, 0, 0, 1, 2, 3, 3, 2, 1, 0, 0]              # row 0 mirrored: edge sample repeated, period 2w
+    assert m[0, 0, :, 2].tolist() == [0, 0, 4, 8, 8, 4, 0, 0]
+    assert torch.equal(U.pad_up_to(x, (3, 4)), x)
+    xg = torch.randn(1, 2, 3, 4, requires_grad=True)
+    U.pad_up_to(xg, (6, 8)).sum().backward()
+    assert torch.equal(xg.grad, torch.full_like(xg, 4.0))
