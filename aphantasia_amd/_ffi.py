@@ -64,6 +64,7 @@ _PROTOTYPES = {
     'aph_vit_set_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     'aph_vit_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'aph_vit_forward_hilo': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'aph_vit_enable_hilo': (c_int, [c_void_p]),
     'aph_vit_backward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     'aph_vit_backward_h': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     'aph_vit_profile': (c_int, [c_void_p, c_int]),
@@ -71,6 +72,8 @@ _PROTOTYPES = {
     'aph_gemm_set_mfma32': (c_int, [c_int]),
     'aph_vit_set_fuse_ln': (c_int, [c_int]),
     'aph_crop_adjoint_set_gather': (c_int, [c_int]),
+    'aph_crop_adjoint_set_shape': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'aph_vit_set_grad_stream_f16': (c_int, [c_int]),
     'aph_gemm_set_ws_min_tiles': (c_int, [c_int]),
     'aph_gemm_set_ws_pgroup': (c_int, [c_int]),
     'aph_gemm_set_rs': (c_int, [c_int]),

@@ -530,7 +530,7 @@ __device__ __forceinline__ int grad_col_of_off(int off, int p) {         // inve
 template <int OUT, int RBQ, int CPT>
 __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __restrict__ gout, float gscale, const int* __restrict__ table,
                                                                  float* __restrict__ grgb, Geom g, const AdjEntry* __restrict__ tab, int maxcs,
-                                                                 int RB, int NBC, int dbg, int XW) {
+                                                                 int RB, int NBC, int dbg, int XW, int center_out) {
   // [r4] XW: columns per workgroup; blockIdx.z selects the column segment [x0, x0 + XW) (frames wider than 768 threads x 3 columns: the
   // 3840-wide C4 frame is two segments; a segment culls the cuts that do not reach it)
   constexpr int RBP = RBQ * 4, MAXV = 512;
@@ -542,7 +542,11 @@ __global__ __launch_bounds__(768) void crop_adjoint_rows_kernel(const void* __re
   int* vbox = vlist + MAXV;                                                    // [MAXV][3] = cs, ox, oy of the listed cuts
   int* vcount = vbox + 3 * MAXV;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int c = blockIdx.y, y0 = blockIdx.x * RB;
+  // [r6] center_out: workgroup i of a (channel, segment) takes row block centre + i / 2 (i even) or centre - (i + 1) / 2 (i odd): with random crops the
+  // middle rows of the frame are covered by the most cuts (1.2x the mean, 3.6x the edge blocks), and a grid with more workgroups than CUs
+  // should start its longest items first
+  const int nrb = gridDim.x, bi = blockIdx.x, rbi = center_out ? ((bi & 1) ? nrb / 2 - (bi + 1) / 2 : nrb / 2 + bi / 2) : bi;
+  const int c = blockIdx.y, y0 = rbi * RB;
   const int x0 = blockIdx.z * XW, x1 = (x0 + XW < g.W ? x0 + XW : g.W);
   const int rows = g.H - y0 < RB ? g.H - y0 : RB;
   const int cchan = is_patch<OUT>::v ? 1 : g.size * g.size;       // channel stride of the gradient layout (patch-major: channel fastest)
@@ -1147,6 +1151,21 @@ inline int& crop_adjoint_gather() {
   return v;
 }
 
+// launch shape of the separable crop adjoint: 0 / -1 = automatic (aph_crop_adjoint_set_shape: the sweep of tools/exp/crop_adjoint_sweep.py)
+struct CropAdjointShape { int rb = 0, cpt = 0, nbc = 0, nseg = 0, order = -1; };
+inline CropAdjointShape& crop_adjoint_shape() {
+  static CropAdjointShape v;
+  return v;
+}
+inline int gemm_like_cu_count() {          // CUs of the current device (256 on MI355X); the interpreter build says 3 so that the centre-out order is exercised
+#ifdef APH_EMU
+  return 3;
+#else
+  static const int n = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return cu > 0 ? cu : 256; }();
+  return n;
+#endif
+}
+
 template <int OUT>
 int launch_crop_adjoint(const void* gout, float gscale, const int* table, float* grgb, const Geom& g, AdjEntry* tab, hipStream_t st) {
   const int maxcs = g.Hp < g.Wp ? g.Hp : g.Wp;
@@ -1154,17 +1173,30 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
   // [r3] frames without wrap padding: the separable row-block kernel (APH_CROP_ADJOINT=gather keeps the round-2 gather kernel for A/B runs)
   if (!crop_adjoint_gather() && g.Hp == g.H && g.Wp == g.W && g.py0 == 0 && g.px0 == 0 && g.W <= 4 * 2304 && g.size <= 256) {
     // column segments of at most 2304 (768 threads x 3 columns); [r4] wider frames (C4: 3840) take several segments per row block
-    const int nseg = (g.W + 2303) / 2304, xw = ((g.W + nseg - 1) / nseg + 3) & ~3;
-    const int cpt = xw <= 1536 ? 2 : 3;                       // columns per thread, at most 768 threads (three waves per SIMD: 168 VGPRs)
+    int nseg = (g.W + 2303) / 2304;
+    const CropAdjointShape& ov = crop_adjoint_shape();
+    if (ov.nseg > 0) nseg = ov.nseg;
+    const int xw = ((g.W + nseg - 1) / nseg + 3) & ~3;
+    int cpt = xw <= 1536 ? 2 : 3;                             // columns per thread, at most 768 threads (three waves per SIMD: 168 VGPRs)
+    if (ov.cpt > 0) cpt = ov.cpt;
     int nthr = (((xw + cpt - 1) / cpt) + 63) / 64 * 64;
     nthr = nthr < 256 ? 256 : nthr;
-    // rows per workgroup: about one workgroup per CU over rows x 3 channels (85 row blocks), 12 or 16 accumulator rows per column
-    // (16 rows x 3 columns needs 168 VGPRs + scratch: segmented frames stay at 12)
+    if (nthr > 768) return aph_fail(APH_ERR_ARG, "crop adjoint: %d columns per segment need more than 768 threads x %d columns", xw, cpt);
+    // rows per workgroup: about one workgroup per CU over rows x 3 channels (85 row blocks), 12 or 16 accumulator rows per column.
+    // [r6] launch-shape sweep (tools/exp/crop_adjoint_sweep.py, profiles/r06_crop_adjoint_sweep.txt): at 1280x720 / 190 cuts the automatic
+    // 9 rows x 2 columns x 1 segment (240 workgroups) is the fastest of 180 shapes (293 us with the tap tables; every finer split of rows or
+    // columns loses: the pass pays per (column, cut) entry, and more rows per workgroup amortise it); at 3840x2160 / 95 cuts 16 rows x
+    // 3 columns x 2 segments takes 495 us against 581 for the 12 rows segmented frames used to be held at (the 168-VGPR concern of round 4
+    // did not materialise: no scratch in the ISA)
     int rb = (g.H + 84) / 85;
     rb = rb < 4 ? 4 : (rb > 16 ? 16 : rb);
-    if (nseg > 1 && rb > 12) rb = 12;
-    const int rbq = rb <= 12 ? 3 : 4, rbp = rbq * 4;
-    int nbc = ADJ_NBC;
+    if (ov.rb > 0) rb = ov.rb;
+    int rbq = rb <= 12 ? 3 : 4;
+#ifdef APH_EXPERIMENTS
+    if (ov.rb > 0) rbq = (rb + 3) / 4;
+#endif
+    const int rbp = rbq * 4;
+    int nbc = ov.nbc > 0 && ov.nbc <= ADJ_NBC ? ov.nbc : ADJ_NBC;
     auto lds = [&](int n) { return (size_t)n * g.size * rbp * 4 + 2 * (size_t)n * rbq * 8 * sizeof(QuadRow) + 2 * (size_t)n * 16 + 512 * 16 + 16; };
     while (nbc > 1 && lds(nbc) > 150 * 1024) --nbc;
     if (lds(nbc) <= 150 * 1024) {
@@ -1175,11 +1207,23 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
       constexpr int dbg = 0;
 #endif
       const size_t smem = lds(nbc);
+      const int center_out = ov.order >= 0 ? ov.order : ((int)(rgrid.x * 3 * nseg) > gemm_like_cu_count() ? 1 : 0);
 #define APH_ADJ_ROWS(RBQ, CPT)                                                                                                              \
   do {                                                                                                                                       \
     APH_ALLOW_SMEM((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), 150 * 1024);                                                                   \
-    APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg, xw); \
+    APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg, xw, center_out); \
   } while (0)
+#ifdef APH_EXPERIMENTS       /* every (rows, columns per thread) shape, for the launch-shape sweep of tools/exp/crop_adjoint_sweep.py */
+      if (rbq == 1 && cpt == 1) APH_ADJ_ROWS(1, 1);
+      else if (rbq == 1 && cpt == 2) APH_ADJ_ROWS(1, 2);
+      else if (rbq == 1) APH_ADJ_ROWS(1, 3);
+      else if (rbq == 2 && cpt == 1) APH_ADJ_ROWS(2, 1);
+      else if (rbq == 2 && cpt == 2) APH_ADJ_ROWS(2, 2);
+      else if (rbq == 2) APH_ADJ_ROWS(2, 3);
+      else if (rbq == 3 && cpt == 1) APH_ADJ_ROWS(3, 1);
+      else if (rbq == 4 && cpt == 1) APH_ADJ_ROWS(4, 1);
+      else
+#endif
       if (rbq == 3 && cpt == 2) APH_ADJ_ROWS(3, 2);
       else if (rbq == 3) APH_ADJ_ROWS(3, 3);
       else if (cpt == 2) APH_ADJ_ROWS(4, 2);
@@ -1196,6 +1240,13 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
 
 extern "C" {
 
+// test / measurement hook: launch shape of the separable crop adjoint (rows per workgroup, columns per thread, cuts per batch, column
+// segments, row-block order 0 = top-down / 1 = centre-out); 0 (order: -1) = automatic.  rb beyond the shipped kernel shapes needs a -DAPH_EXPERIMENTS build.
+int aph_crop_adjoint_set_shape(int rb, int cpt, int nbc, int nseg, int order) {
+  CropAdjointShape& v = crop_adjoint_shape();
+  v.rb = rb; v.cpt = cpt; v.nbc = nbc; v.nseg = nseg; v.order = order;
+  return APH_OK;
+}
 // test / measurement hook: 1 = the crop adjoint always runs the gather kernel, 0 = automatic.  Returns the previous value.
 int aph_crop_adjoint_set_gather(int on) {
   const int prev = crop_adjoint_gather();

@@ -51,6 +51,8 @@ struct aph_vit {
   SplitKSpace sk;                      // split-K partials of the small-M GEMMs (per-rank shards, class-row GEMMs)
   char* arena = nullptr;
   size_t arena_bytes = 0;
+  char* arena_hilo = nullptr;          // [r6] the K-repeated weight copies of the split-precision forward (w_patch2, w_qkv2): allocated by aph_vit_enable_hilo only
+  size_t arena_hilo_bytes = 0;
   int n_set = 0;
   // optional per-launch timing of the GEMM family (bench.py roofline): HIP event pairs on the launch stream
   bool prof_on = false;
@@ -70,16 +72,33 @@ struct Carver {
   }
 };
 
+// the second arena (aph_vit_enable_hilo): [N, 2 K] copies of the patch-embedding and QKV weights, every row twice along K -- the B operand of
+// a GEMM over [hi | lo] activation rows.  85 MB at ViT-B/32 that the default (f16 everywhere) path never touches.
+void carve_hilo(aph_vit* v, char* base, size_t* total) {
+  Carver c{base};
+  const size_t D = v->D, Kp = v->Kp;
+  v->w_patch2 = c.take<half_t>(2 * D * Kp);
+  for (auto& l : v->layers) l.w_qkv2 = c.take<half_t>(6 * D * D);
+  *total = c.off;
+}
+// device [rows, cols] f16 -> device [rows, 2 cols]: every row twice along K
+int repeat_rows_k(half_t* dst, const half_t* src, size_t rows, size_t cols) {
+  const size_t w = cols * sizeof(half_t);
+  if (hipMemcpy2D(dst, 2 * w, src, w, w, rows, hipMemcpyDeviceToDevice) != hipSuccess) return -1;
+  if (hipMemcpy2D(reinterpret_cast<char*>(dst) + w, 2 * w, src, w, w, rows, hipMemcpyDeviceToDevice) != hipSuccess) return -1;
+  return 0;
+}
+
 void carve(aph_vit* v, char* base, size_t* total) {
   Carver c{base};
   const size_t D = v->D, Mx = (size_t)v->max_batch * v->T, E = v->E, Kp = v->Kp, T = v->T;
-  v->w_patch = c.take<half_t>(D * Kp); v->w_patchT = c.take<half_t>(D * Kp); v->w_patch2 = c.take<half_t>(2 * D * Kp);
+  v->w_patch = c.take<half_t>(D * Kp); v->w_patchT = c.take<half_t>(D * Kp);
   v->cls = c.take<float>(D); v->pos = c.take<float>(T * D);
   v->ln_pre_g = c.take<float>(D); v->ln_pre_b = c.take<float>(D);
   v->ln_post_g = c.take<float>(D); v->ln_post_b = c.take<float>(D);
   v->proj = c.take<float>(D * E); v->projT = c.take<float>(D * E);
   for (auto& l : v->layers) {
-    l.w_qkv = c.take<half_t>(3 * D * D); l.w_qkvT = c.take<half_t>(3 * D * D); l.w_qkv2 = c.take<half_t>(6 * D * D);
+    l.w_qkv = c.take<half_t>(3 * D * D); l.w_qkvT = c.take<half_t>(3 * D * D);
     l.w_o = c.take<half_t>(D * D); l.w_oT = c.take<half_t>(D * D);
     l.w_fc1 = c.take<half_t>(4 * D * D); l.w_fc1T = c.take<half_t>(4 * D * D);
     l.w_fc2 = c.take<half_t>(4 * D * D); l.w_fc2T = c.take<half_t>(4 * D * D);
@@ -90,8 +109,11 @@ void carve(aph_vit* v, char* base, size_t* total) {
   }
   v->x0 = c.take<float>(Mx * D); v->x_last = c.take<float>(Mx * D);
   v->h = c.take<half_t>(Mx * 2 * D); v->gact = c.take<half_t>(Mx * 4 * D);      // h: [hi | lo] rows in the split-precision forward
-  v->dx = c.take<float>(Mx * D); v->dx2 = c.take<float>(Mx * D);
+  v->dx = c.take<float>(Mx * D);
+#ifdef APH_EXPERIMENTS       // scratch of measured-and-not-adopted paths only: the fused backward's hand-over buffer, the two-kernel attention backward's row dots
+  v->dx2 = c.take<float>(Mx * D);
   v->delta = c.take<float>((size_t)v->max_batch * v->heads * T);
+#endif
   v->dx16 = c.take<half_t>(Mx * D); v->du = c.take<half_t>(Mx * 4 * D); v->dh = c.take<half_t>(Mx * D);
   v->datt = c.take<half_t>(Mx * D); v->dqkv = c.take<half_t>(Mx * 3 * D); v->dx0_16 = c.take<half_t>(Mx * D);
   v->sk.ws_floats = (size_t)256 * GemmSmall::BM * GemmSmall::BN;       // choose_splits keeps tiles * splits <= 256
@@ -213,19 +235,21 @@ void launch_ln_fwd(int nv, const float* x, const float* g, const float* b, void*
 }
 // res_T: residual on the rows with row % res_T == 0 only;  x_b / g_b: the previous LayerNorm's backward fused behind this one (ln_bwd_kernel)
 template <bool DY_F16, bool PATCH>
-void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const float* res, float* out32, half_t* out16, int M,
-                   int T, hipStream_t st, int xs = 1, int res_T = 0, const float* x_b = nullptr, const float* g_b = nullptr) {
+void launch_ln_bwd(int nv, const void* dy, const float* x, const float* g, const void* res, float* out32, half_t* out16, int M,
+                   int T, hipStream_t st, int xs = 1, int res_T = 0, const float* x_b = nullptr, const float* g_b = nullptr, int res_f16 = 0) {
   const dim3 grid((M + 3) / 4), block(256);
   switch (nv) {
-    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
-    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
-    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
-    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b); break;
+    case 1: APH_LAUNCH((ln_bwd_kernel<1, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b, res_f16); break;
+    case 2: APH_LAUNCH((ln_bwd_kernel<2, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b, res_f16); break;
+    case 3: APH_LAUNCH((ln_bwd_kernel<3, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b, res_f16); break;
+    default: APH_LAUNCH((ln_bwd_kernel<4, DY_F16, PATCH>), grid, block, 0, st, dy, x, g, res, out32, out16, M, T, xs, res_T, x_b, g_b, res_f16); break;
   }
 }
 // LayerNorm pairs of the first block as one kernel each way, and no zero fill of the fp32 gradient stream (aph_vit_set_fuse_ln(0): the
 // separate kernels -- bit-identical, kept for the equivalence test)
 int g_fuse_ln = 1;
+// [r6] measurement switch (aph_vit_set_grad_stream_f16): the backward's residual-stream gradient kept in f16 only (see ln_bwd_kernel res_f16)
+int g_grad_stream_f16 = 0;
 
 // attention launches: T <= 64 one-tile kernels, 64 < T <= 256 the blocked kernels (NB = ceil(T / 64))
 struct AttnArgs {
@@ -343,11 +367,39 @@ int aph_vit_destroy(aph_vit* v) {
   if (!v) return APH_OK;
   for (hipEvent_t e : v->prof_ev) (void)hipEventDestroy(e);
   (void)hipFree(v->arena);
+  if (v->arena_hilo) (void)hipFree(v->arena_hilo);
   delete v;
   return APH_OK;
 }
 
-size_t aph_vit_workspace_bytes(const aph_vit* v) { return v ? v->arena_bytes : 0; }
+// [r6] Allocates and fills the K-repeated weight copies aph_vit_forward_hilo multiplies [hi | lo] activation rows with (85 MB at ViT-B/32).
+// Call once, after the weights are loaded and outside any stream capture (it allocates and copies synchronously); idempotent.  The default
+// path (aph_vit_forward: f16 operands everywhere) never needs it -- round 5 carried these copies in every handle.
+int aph_vit_enable_hilo(aph_vit* v) {
+  APH_TRY
+  if (!v) return aph_fail(APH_ERR_ARG, "aph_vit_enable_hilo: null handle");
+  if (v->arena_hilo) return APH_OK;
+  if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_enable_hilo: weights not fully loaded (%d tensors)", v->n_set);
+  size_t total = 0;
+  carve_hilo(v, nullptr, &total);
+  char* base = nullptr;
+  const hipError_t me = hipMalloc((void**)&base, total);
+  if (me != hipSuccess) { carve_hilo(v, nullptr, &total); return aph_fail(APH_ERR_HIP, "aph_vit_enable_hilo: cannot allocate %zu bytes (%s)", total, hipGetErrorString(me)); }
+  carve_hilo(v, base, &total);
+  int rc = repeat_rows_k(v->w_patch2, v->w_patch, v->D, v->Kp);
+  for (auto& l : v->layers) rc |= repeat_rows_k(l.w_qkv2, l.w_qkv, 3 * (size_t)v->D, v->D);
+  if (rc || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(base);
+    carve_hilo(v, nullptr, &total);          // back to null pointers
+    return aph_fail(APH_ERR_HIP, "aph_vit_enable_hilo: device copy failed");
+  }
+  v->arena_hilo = base;
+  v->arena_hilo_bytes = total;
+  return APH_OK;
+  APH_CATCH
+}
+
+size_t aph_vit_workspace_bytes(const aph_vit* v) { return v ? v->arena_bytes + v->arena_hilo_bytes : 0; }
 
 // Upload one tensor by its OpenAI checkpoint key (without the `visual.` prefix), fp32 host data.
 // e.g. "conv1.weight", "transformer.resblocks.3.attn.in_proj_weight", "proj".
@@ -366,7 +418,7 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
     for (size_t d = 0; d < D; ++d)
       for (size_t c = 0; c < 3; ++c)
         for (size_t q = 0; q < pp; ++q) perm[d * Kp + q * 3 + c] = data[d * Kp + c * pp + q];
-    rc = upload_f16(v->w_patch, perm.data(), D, Kp, false) | upload_f16(v->w_patchT, perm.data(), D, Kp, true) | upload_f16_twice(v->w_patch2, perm.data(), D, Kp);
+    rc = upload_f16(v->w_patch, perm.data(), D, Kp, false) | upload_f16(v->w_patchT, perm.data(), D, Kp, true) | (v->w_patch2 ? upload_f16_twice(v->w_patch2, perm.data(), D, Kp) : 0);
   }
   else if (n == "class_embedding") { if ((rc = need(D))) return rc; rc = upload_f32(v->cls, data, 1, D, false); }
   else if (n == "positional_embedding") { if ((rc = need(T * D))) return rc; rc = upload_f32(v->pos, data, T, D, false); }
@@ -383,7 +435,7 @@ int aph_vit_set_weight(aph_vit* v, const char* name, const float* data, size_t c
     if (li < 0 || li >= v->L) return aph_fail(APH_ERR_ARG, "aph_vit_set_weight: layer %d out of range", li);
     Layer& l = v->layers[li];
     const std::string k = n.substr(dot + 1);
-    if (k == "attn.in_proj_weight") { if ((rc = need(3 * D * D))) return rc; rc = upload_f16(l.w_qkv, data, 3 * D, D, false) | upload_f16(l.w_qkvT, data, 3 * D, D, true) | upload_f16_twice(l.w_qkv2, data, 3 * D, D); }
+    if (k == "attn.in_proj_weight") { if ((rc = need(3 * D * D))) return rc; rc = upload_f16(l.w_qkv, data, 3 * D, D, false) | upload_f16(l.w_qkvT, data, 3 * D, D, true) | (l.w_qkv2 ? upload_f16_twice(l.w_qkv2, data, 3 * D, D) : 0); }
     else if (k == "attn.in_proj_bias") { if ((rc = need(3 * D))) return rc; rc = upload_f32(l.b_qkv, data, 1, 3 * D, false); }
     else if (k == "attn.out_proj.weight") { if ((rc = need(D * D))) return rc; rc = upload_f16(l.w_o, data, D, D, false) | upload_f16(l.w_oT, data, D, D, true); }
     else if (k == "attn.out_proj.bias") { if ((rc = need(D))) return rc; rc = upload_f32(l.b_o, data, 1, D, false); }
@@ -412,10 +464,13 @@ static int vit_forward_impl(aph_vit* v, const void* d_patches, int S, float* d_e
   if (!v || !d_patches || !d_enc) return aph_fail(APH_ERR_ARG, "aph_vit_forward: null argument");
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_forward: batch %d outside 1..%d", S, v->max_batch);
   if (v->n_set < 8 + 12 * v->L) return aph_fail(APH_ERR_ARG, "aph_vit_forward: weights not fully loaded (%d tensors)", v->n_set);
+  if (hilo && !v->arena_hilo)
+    return aph_fail(APH_ERR_ARG, "aph_vit_forward_hilo: call aph_vit_enable_hilo(vit) once after loading the weights (the split-precision forward's "
+                    "K-repeated weight copies are not allocated by default)");
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
   const int kx = hilo ? 2 : 1;
-  gemm_rs_small_batch() = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
+  v->sk.small_batch = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   vgemm(v, (const half_t*)d_patches, kx * v->Kp, hilo ? v->w_patch2 : v->w_patch, kx * v->Kp, S * v->P, D, kx * v->Kp, EpiPatchEmbed{v->x0, v->pos, D, v->P, T}, st, kx);
   const bool fuse = g_fuse_ln != 0;
   const bool blk = !hilo && vit_fused(v, S);          // fused block kernels: LayerNorm inside the QKV / fc1 launches, attention behind the QKV GEMM
@@ -494,10 +549,11 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
   if (S < 1 || S > v->max_batch) return aph_fail(APH_ERR_ARG, "aph_vit_backward: batch %d outside 1..%d", S, v->max_batch);
   hipStream_t st = (hipStream_t)stream_;
   const int D = v->D, T = v->T, M = S * T, nv = D / 256;
-  gemm_rs_small_batch() = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
+  v->sk.small_batch = M <= 128;   // see gemm_rs_mode(): the split-K small-M kernel only when the whole batch is small
   // only the class rows carry gradient out of the head: the fp32 stream starts from zero; dx16 needs no clearing -- the
   // last block reads and writes its class rows only (row pitch T), and its ln_1 backward rewrites every row
   const bool fuse = g_fuse_ln != 0;      // (then the last block's ln_1 backward takes its residual from the class rows only: no fill)
+  const int s16 = (g_grad_stream_f16 != 0 && fuse && !vit_fused(v, S)) ? 1 : 0;      // f16-only gradient stream (measurement switch; needs the fused LayerNorm pairs' row conventions)
   if (!fuse) zero_fill_async(v->dx, sizeof(float) * (size_t)M * D, st);            // (a kernel node, not a memset node: see zero_fill_async)
   APH_LAUNCH(head_bwd_kernel, dim3(S), dim3(D), sizeof(float) * v->E, st, d_genc, (const float*)v->x_last,
              (const float*)v->ln_post_g, (const float*)v->projT, v->dx, v->dx16, T, D, v->E);
@@ -526,7 +582,8 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
       vgemm(v, v->dx16, rs * D, l.w_fc2T, D, Mr, 4 * D, D, EpiGeluBwd{v->du, l.u, 4 * D}, st);
     }
     vgemm(v, v->du, 4 * D, l.w_fc1T, 4 * D, Mr, D, 4 * D, EpiF16{v->dh, D, nullptr}, st);
-    launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, res2, v->dx, v->dx16, Mr, T, st, rs);
+    if (s16) launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, v->dx16, nullptr, v->dx16, Mr, T, st, rs, 0, nullptr, nullptr, 1);
+    else launch_ln_bwd<true, false>(nv, v->dh, l.x_mid, l.ln2_g, res2, v->dx, v->dx16, Mr, T, st, rs);
     vgemm(v, v->dx16, rs * D, l.w_oT, D, Mr, D, D, EpiF16{v->datt, rs * D, nullptr}, st);
     launch_attn_bwd(attn_args(v, l, S), st);
     vgemm(v, v->dqkv, 3 * D, l.w_qkvT, 3 * D, M, D, 3 * D, EpiF16{v->dh, D, nullptr}, st);
@@ -535,7 +592,9 @@ static int vit_backward_impl(aph_vit* v, const float* d_genc, int S, void* d_pat
       pending_res_T = (fuse && cls_only) ? T : 0;
     }
     else if (fuse && li == 0)      // ln_1 backward and ln_pre backward as one kernel: writes the patch rows of dx0_16 only
-      launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, nullptr, v->dx0_16, M, T, st, 1, cls_only ? T : 0, v->x0, v->ln_pre_g);
+      launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, s16 ? (const void*)v->dx16 : (const void*)v->dx, nullptr, v->dx0_16, M, T, st, 1, cls_only ? T : 0, v->x0, v->ln_pre_g, s16);
+    else if (s16)
+      launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx16, nullptr, v->dx16, M, T, st, 1, cls_only ? T : 0, nullptr, nullptr, 1);
     else
       launch_ln_bwd<true, false>(nv, v->dh, l.x_in, l.ln1_g, v->dx, v->dx, v->dx16, M, T, st, 1, (fuse && cls_only) ? T : 0);
   }
@@ -586,6 +645,14 @@ int aph_vit_profile_read(aph_vit* v, double* ms_total, long long* launches, doub
 int aph_vit_set_fuse_ln(int on) {
   const int prev = g_fuse_ln;
   g_fuse_ln = on ? 1 : 0;
+  return prev;
+}
+
+// [r6] 1 = the backward keeps its residual-stream gradient in f16 only (each LayerNorm backward reads the f16 copy its predecessor wrote and
+// writes no fp32 stream); 0 (default) = fp32 stream.  Returns the previous value.  A measurement switch: see DESIGN.md section 4 *Round 6*.
+int aph_vit_set_grad_stream_f16(int on) {
+  const int prev = g_grad_stream_f16;
+  g_grad_stream_f16 = on ? 1 : 0;
   return prev;
 }
 
@@ -775,13 +842,18 @@ int aph_gemm_f16(const void* d_A, const void* d_Bt, int M, int N, int K, float* 
 // 10 = 128x128 4-stage, 11 = 128x128 4 waves 2-stage (two workgroups per CU), 12 = 256x128 on 4 waves,
 // 14 / 15 = 64x64 register-staged split-K (4 / 3 k-steps in flight per wave), 16 / 17 = 64x256 A-resident (8 / 4 k-steps in flight; N % 256 == 0, K <= 1024),
 // 22 / 24 = 128x128 split-K x2 / x4) -- unit tests and tuning sweeps
+#ifdef APH_EXPERIMENTS
+static bool gemm_ar_addressable(int N, int K) { return gemm_ar_fits(N, K); }
+#else
+static bool gemm_ar_addressable(int, int) { return true; }      // (tile_cfg 16 / 17 are refused further down in product builds)
+#endif
 int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, int N, int K, float* d_C, int tile_cfg, void* stream_) {
   APH_TRY
   const bool nostore = (tile_cfg & 0x100) != 0;
   tile_cfg &= 0xff;
   if (!d_A || !d_Bt || !d_C || M < 1 || N % 128 || K % GEMM_BK || N < 1 || K < 1 || lda < K || ldb < K || (lda & 7) || (ldb & 7) ||
       !(tile_cfg == 0 || tile_cfg == 1 || tile_cfg == 2 || tile_cfg == 4 || tile_cfg == 5 || (tile_cfg >= 8 && tile_cfg <= 12) || (tile_cfg >= 14 && tile_cfg <= 17) || tile_cfg == 22 || tile_cfg == 24) ||
-      (tile_cfg >= 14 && tile_cfg <= 17 && !gemm8_addressable(M, lda, N, ldb)) || (tile_cfg >= 14 && tile_cfg <= 15 && !gemm_sk_fits(N, K)) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
+      (tile_cfg >= 14 && tile_cfg <= 17 && !gemm8_addressable(M, lda, N, ldb)) || (tile_cfg >= 14 && tile_cfg <= 15 && !gemm_sk_fits(N, K)) || (tile_cfg >= 16 && tile_cfg <= 17 && !gemm_ar_addressable(N, K)) || (tile_cfg == 4 && (N % 256 || !gemm8_addressable(M, lda, N, ldb))) || (tile_cfg == 5 && (!gemm8_addressable(M, lda, N, ldb) || N > GemmWS::BIAS_MAX)))
     return aph_fail(APH_ERR_ARG, "aph_gemm_f16_ld: bad shape");
   const half_t* A = (const half_t*)d_A;
   const half_t* B = (const half_t*)d_Bt;

@@ -690,6 +690,10 @@ inline void launch_gemm_cfg(const half_t* A, int lda, const half_t* Bt, int ldb,
 struct SplitKSpace {
   float* ws = nullptr;
   size_t ws_floats = 0;
+  // the WHOLE batch of the ViT call these launches belong to is at most 128 token rows (one or two cuts): written by aph_vit_forward /
+  // aph_vit_backward into their own handle's space, read by launch_gemm -- per call, not process-wide (two engines on two host threads
+  // no longer race on it).  Stand-alone GEMM calls (the test entries, no space) count as small batches.
+  bool small_batch = true;
 };
 
 // how many ways to split K for the 64x64 configuration: only when the tiles alone occupy a small part of the chip (the
@@ -784,7 +788,7 @@ inline int& gemm_ws_min_tiles() {
 }
 
 // The register-staged kernels of vit_gemm_rs.h.  gemm_rs_mode(): 1 (default) = the split-K kernel for GEMMs of at most 128 rows over
-// K <= 1024 WHEN THE WHOLE BATCH IS THAT SMALL (gemm_rs_small_batch(), set by the ViT entry points from cuts x tokens: one or two cuts,
+// K <= 1024 WHEN THE WHOLE BATCH IS THAT SMALL (SplitKSpace::small_batch, set by the ViT entry points from cuts x tokens: one or two cuts,
 // C1): one launch with an ordered in-kernel reduction instead of a split-K launch plus its reduce launch (C1 577 -> 726 steps/s).  Over
 // K = 3072 the two-pass split-K stays: its 48 workgroups pull the cold weight matrix through four times as many CUs (11.3 against 20 us,
 // profiles/r05_kernel_stats_s26_fused_v4.csv).  The class-row GEMMs of a LARGER batch's last block (M = cuts) stay on the two-pass
@@ -793,10 +797,6 @@ inline int& gemm_ws_min_tiles() {
 // (profiles/r05_stress_rs_ab.txt, r05_stress_rs_dense.txt; against fp64 this kernel is the more accurate of the two), and the order with
 // the margin under north_star's 1e-3 is worth more than 0.7 % of a shard's step;
 // 2 = every shape the register-staged kernels address (the A/B switch of bench.py --vit-path rs and the test hook); 0 = off.
-inline bool& gemm_rs_small_batch() {
-  static bool small = true;  // stand-alone GEMM calls (the test hook) count as small batches
-  return small;
-}
 inline int& gemm_rs_mode() {
   static int v = 1;
   return v;
@@ -815,7 +815,7 @@ inline void launch_gemm(const half_t* A, int lda, const half_t* Bt, int ldb, int
     launch_gemm_ws(A, lda, Bt, ldb, M, N, K, epi, st);
     return;
   }
-  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || (gemm_rs_small_batch() && M <= 128 && K <= 1024)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
+  if (gemm_rs_mode() && (gemm_rs_mode() > 1 || ((sp ? sp->small_batch : true) && M <= 128 && K <= 1024)) && gemm8_addressable(M, lda, N, ldb) && !gemm_mfma32() &&
       launch_gemm_rs_auto(A, lda, Bt, ldb, M, N, K, epi, st, gemm_rs_mode() > 1))
     return;
   const int mid_tiles = (N / GemmMidDeep8::BN) * ((M + GemmMidDeep8::BM - 1) / GemmMidDeep8::BM);

@@ -114,8 +114,12 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 //           block's ln_1 backward followed by ln_pre's as one kernel (the same arithmetic on the same fp32 values: bit-identical).
 template <int NV, bool DY_F16, bool PATCH_ROWS>
 __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                              const float* __restrict__ res, float* __restrict__ out32, half_t* __restrict__ out16, int M, int T,
-                              int xs, int res_T = 0, const float* __restrict__ x_b = nullptr, const float* __restrict__ gamma_b = nullptr) {
+                              const void* res, float* __restrict__ out32, half_t* out16, int M, int T,
+                              int xs, int res_T = 0, const float* __restrict__ x_b = nullptr, const float* __restrict__ gamma_b = nullptr, int res_f16 = 0) {
+  // res_f16 [r6, measurement switch aph_vit_set_grad_stream_f16]: the incoming residual-stream gradient is the f16 copy the previous
+  // LayerNorm backward wrote for its dgrad GEMM (`res` may then alias out16: a lane reads its elements before it writes them), and no
+  // fp32 stream is kept (out32 = NULL): 73 instead of 117 MB per launch at 190 cuts -- at the price of one f16 rounding of the stream
+  // per LayerNorm (24 of them); see DESIGN.md section 4 *Round 6* for what the loss-curve ensemble says about it
   constexpr int D = 256 * NV;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -164,7 +168,14 @@ __global__ void ln_bwd_kernel(const void* __restrict__ dy, const float* __restri
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - sg - v[i][j] * sgx);
-    if (res && (res_T == 0 || row % res_T == 0)) o += *reinterpret_cast<const f32x4*>(res + srow * D + d);
+    if (res && (res_T == 0 || row % res_T == 0)) {
+      if (res_f16) {
+        const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(res) + srow * D + d);
+        o += f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(res) + srow * D + d);
+      }
+    }
     if (!PATCH_ROWS && x_b) { g[i] = o; continue; }
     if (out32) *reinterpret_cast<f32x4*>(out32 + srow * D + d) = o;
     if (out16) {

@@ -136,6 +136,8 @@ class Engine:
         self.set_targets(targets)
         # static buffers
         self.visual.ensure_batch(max(self.S_loc, 1))
+        if precise:
+            self.visual.handle.enable_hilo()          # allocates the K-repeated weight copies: here, not inside a captured step
         g = self.size // self.patch
         self.P, self.Kp = g * g, 3 * self.patch * self.patch
         D = self.visual.output_dim

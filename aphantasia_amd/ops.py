@@ -207,6 +207,15 @@ class VitHandle:
             self.lib.call('aph_vit_set_weight', self.handle, k.encode(), a.ctypes.data_as(c_void_p), a.size)
         g = cfg['input_resolution'] // cfg['patch_size']
         self.P, self.T, self.Kp = g * g, g * g + 1, 3 * cfg['patch_size'] ** 2
+        self._hilo = False
+
+    def enable_hilo(self):
+        """the K-repeated weight copies of the split-precision forward (aph_vit_enable_hilo: 85 MB at ViT-B/32, not carried by default)"""
+        if not self._hilo:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('VitHandle.enable_hilo() allocates: call it before the step is captured into a graph')
+            self.lib.call('aph_vit_enable_hilo', self.handle)
+            self._hilo = True
 
     def workspace_bytes(self):
         return int(self.lib.cdll.aph_vit_workspace_bytes(self.handle))
@@ -218,6 +227,8 @@ class VitHandle:
         want = (2 if hilo else 1) * self.Kp
         if patches.shape[-1] != want:
             raise ValueError('VitHandle.forward(hilo=%s): patch rows of %d halfs, expected %d' % (hilo, patches.shape[-1], want))
+        if hilo:
+            self.enable_hilo()
         self.lib.call('aph_vit_forward_hilo' if hilo else 'aph_vit_forward', self.handle, ptr(patches), int(S), ptr(out), _stream(patches))
         return out
 

@@ -76,8 +76,9 @@ def get_args(argv=None):
     parser.add_argument(       '--clip-weights2', dest='clip_weights2', default=None, help='checkpoint of the --dualmod model (ViT-B-16.pt)')
     parser.add_argument(       '--seed',    default=None, type=int, help='seed torch/numpy RNG (reference: unseeded)')
     parser.add_argument(       '--no_save', action='store_true', help='do not write the per-step JPEG frames')
-    parser.add_argument(       '--precise', action='store_true', help='(the default; kept for compatibility) split-precision ViT forward: hi + lo f16 operands on the patch-embedding and QKV GEMMs -- holds the loss curve within 1e-3 of the fp32 CPU reference on weights with large dynamic range')
-    parser.add_argument(       '--fast-f16', action='store_true', help='f16 operands on every ViT GEMM (what the reference runs CLIP at on a GPU): ~5 %% faster, loss curve within 2e-3 instead of 1e-3 on stress weights')
+    parser.add_argument(       '--precise', action='store_true', help='opt-in split-precision ViT forward (patch-embedding and QKV GEMMs on hi + lo f16 activation pairs): ~5 %% slower, lower single-step gradient error; '
+                               'on the stress-weight loss-curve ensemble not significantly closer to the fp32 CPU reference than the default')
+    parser.add_argument(       '--fast-f16', action='store_true', help='(the default since round 6; accepted for old command lines) f16 operands on every ViT GEMM, as the reference runs CLIP on a GPU')
     parser.add_argument(       '--aest-weights', dest='aest_weights', default=None, help="state dict of the LAION aesthetic head (sa_0_4_vit_b_32_linear.pth: "
                                "{'weight': [1,512], 'bias': [1]}); upstream downloads it (utils.py:402-413), there is no network here")
     parser.add_argument(       '--aest-weights2', dest='aest_weights2', default=None, help='the head of the --dualmod model (sa_0_4_vit_b_16_linear.pth)')
@@ -140,7 +141,12 @@ class FrameWriter:
     THREADS = 4        # (8 threads measured the same with-save rate: 153.6-154.0 vs 153.2 steps/s -- the encoders are not the limit)
     RING = 16          # slots of (device uint8 buffer, pinned host buffer); a slot is reused only after its writer released it (below)
 
-    def __init__(self, h, w):
+    def __init__(self, h, w, switch_interval=5e-4):
+        # The encoder threads spend most of their time inside PIL's C encoder (GIL released) but take the GIL for the Python around it; with the
+        # interpreter's default 5 ms switch interval the optimisation loop's thread can wait that long for it while the GPU idles.  0.5 ms keeps
+        # the loop's host work (0.2 ms per step) ahead of the 6 ms step.  None = leave the interpreter's setting alone.
+        if switch_interval is not None and sys.getswitchinterval() > switch_interval:
+            sys.setswitchinterval(switch_interval)
         self.q = queue.Queue(maxsize=8)
         self.h, self.w = h, w
         self.bufs = [torch.empty(h, w, 3, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
@@ -339,13 +345,13 @@ def main(argv=None):
         leaf = params[0]
     eng = Engine(leaf, h, w, model_clip, a.samples, targets, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                  optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                 rank=rank, world=world, comm=comm, aest=aest1, precise=not a.fast_f16, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
+                 rank=rank, world=world, comm=comm, aest=aest1, precise=a.precise, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
     h, w = eng.h, eng.w
     eng2 = None
     if a.dualmod is not None:
         eng2 = Engine(leaf, h, w, model_clip2, a.samples, targets2, sim=a.sim, colors=a.colors, decay=a.decay, lr=lr0,
                       optimizer=a.optimizer, align=a.align, macro=a.macro, transform=trform_f, state=eng.state(), sharp=a.sharp, expand=a.expand, enforce=a.enforce, rng=a.rng,
-                      rank=rank, world=world, comm=comm, aest=aest2, precise=not a.fast_f16, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
+                      rank=rank, world=world, comm=comm, aest=aest2, precise=a.precise, graph_allreduce=a.graph_allreduce or None, use_graph=not a.no_graph, **pk)
 
     writer = None if a.no_save else FrameWriter(h, w)
     # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp

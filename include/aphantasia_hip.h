@@ -179,14 +179,19 @@ size_t aph_vit_workspace_bytes(const aph_vit* vit);
 int aph_vit_set_weight(aph_vit* vit, const char* name, const float* h_data, size_t count);
 /* d_patches f16 [S*P, 3*patch^2] (APH_OUT_PATCH_F16 layout) -> d_enc f32 [S, output_dim] */
 int aph_vit_forward(aph_vit* vit, const void* d_patches, int S, float* d_enc, void* stream);
-/* SPLIT-PRECISION forward (the default of this repo's clip_fft.py and bench.py since round 5; --fast-f16 / --f16 select aph_vit_forward):
- * d_patches_hilo f16 [S*P, 2 * 3*patch^2] (APH_OUT_PATCH_F16_HILO rows [hi | lo]).  The patch-embedding GEMM and every block's QKV GEMM take
- * their activation operand as a hi + lo pair of f16 values (~22 bits; the GEMMs run over twice the K against the weights repeated along K):
- * the two f16 roundings that dominate the input-gradient error on weights with realistic dynamic range (profiles/r04_precision_attribution.txt).
- * At full batch the lo half feeds the Q and K columns of the QKV GEMM only -- the V column tiles run over the hi half, in the same launch
- * (DESIGN.md section 4 *Precision* [r5]).  Same outputs / saved activations as aph_vit_forward; the backward (aph_vit_backward) is unchanged.
- * Costs ~5 % of a C2 step. */
+/* SPLIT-PRECISION forward (opt-in: clip_fft.py --precise, bench.py --split; the default is aph_vit_forward -- f16 operands everywhere, the
+ * reference's own GPU dtype -- since round 6): d_patches_hilo f16 [S*P, 2 * 3*patch^2] (APH_OUT_PATCH_F16_HILO rows [hi | lo]).  The
+ * patch-embedding GEMM and every block's QKV GEMM take their activation operand as a hi + lo pair of f16 values (~22 bits; the GEMMs run over
+ * twice the K against the weights repeated along K): the two f16 roundings that dominate the input-gradient error on weights with realistic
+ * dynamic range (profiles/r04_precision_attribution.txt; single-step input-gradient error 7.7e-4 against 1.10e-3).  At full batch the lo half
+ * feeds the Q and K columns of the QKV GEMM only -- the V column tiles run over the hi half, in the same launch (DESIGN.md section 4
+ * *Precision* [r5]).  Same outputs / saved activations as aph_vit_forward; the backward (aph_vit_backward) is unchanged.  Costs ~5 % of a C2
+ * step; over the 30-member stress-weight loss-curve ensemble its free-running curves are not significantly closer to the fp32 CPU reference
+ * than the default's (profiles/r06_precision_ensemble.txt), which is why it is no longer the default.  Needs aph_vit_enable_hilo once. */
 int aph_vit_forward_hilo(aph_vit* vit, const void* d_patches_hilo, int S, float* d_enc, void* stream);
+/* [r6] Allocates and fills the K-repeated copies of the patch-embedding / QKV weights aph_vit_forward_hilo needs (85 MB at ViT-B/32; a handle
+ * does not carry them by default).  Once per handle, after aph_vit_set_weight of every tensor, outside any stream capture; idempotent. */
+int aph_vit_enable_hilo(aph_vit* vit);
 /* d_genc f32 [S, output_dim] (times the caller's loss scale) -> d_patch_grad f32 [S*P, 3*patch^2] times out_scale */
 int aph_vit_backward(aph_vit* vit, const float* d_genc, int S, float* d_patch_grad, float out_scale, void* stream);
 /* same with the patch gradient stored as f16 (keep the loss scale in it: out_scale = 1, and undo it in aph_sample_bwd's

@@ -45,6 +45,10 @@ int aph_gemm_f16_ld(const void* d_A, int lda, const void* d_Bt, int ldb, int M, 
  * on frames without wrap padding).  Process-wide, returns the previous value.  (No environment variable changes which kernels the library
  * runs: every switch here is an explicit call.) */
 int aph_crop_adjoint_set_gather(int on);
+/* Launch shape of the separable crop adjoint: rows per workgroup (rb), columns per thread (cpt), cuts per batch (nbc), column segments (nseg),
+ * row-block order (0 = top-down, 1 = centre-out); 0 (order: -1) = automatic.  Shapes other than the shipped ones need a -DAPH_EXPERIMENTS build
+ * (tools/exp/crop_adjoint_sweep.py). */
+int aph_crop_adjoint_set_shape(int rb, int cpt, int nbc, int nseg, int order);
 
 /* MFMA shape of the main loops of the GEMM TEST ENTRIES (aph_gemm_f16, aph_gemm_f16_ld; the ViT's own GEMMs are compiled for the default
  * only) launched from now on: 0 = v_mfma_f32_16x16x32_f16 (default: measured
@@ -55,12 +59,18 @@ int aph_gemm_set_mfma32(int on);
  * fp32 gradient stream: on (1, default) / off (0).  Bit-identical either way.
  * Returns the previous value.  Captured graphs keep the setting they were recorded with. */
 int aph_vit_set_fuse_ln(int on);
+/* [r6] 1 = the ViT backward keeps its residual-stream gradient in f16 only (every LayerNorm backward reads the f16 copy its predecessor wrote
+ * for the dgrad GEMM and writes no fp32 stream: 73 instead of 117 MB per launch at 190 cuts); 0 (default) = fp32 stream.  Measurement switch for
+ * the loss-curve ensemble (tools/loss_ensemble.py); returns the previous value.  Captured graphs keep the setting they were recorded with. */
+int aph_vit_set_grad_stream_f16(int on);
 /* Number of 256x128 output tiles from which the shape heuristic picks the wave-specialised persistent kernel (tile_cfg 5)
  * for the ViT's own GEMMs; 0 = never.  Process-wide, returns the previous value (A/B measurements, unit tests at small sizes). */
 int aph_gemm_set_ws_min_tiles(int tiles);
-/* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows (class-row
- * GEMMs over K <= 1024 of the last block, one-cut batches), 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
- * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  Returns the previous value. */
+/* Register-staged GEMMs (tile_cfg 14 / 16) inside the ViT: 1 (default) = the split-K kernel for GEMMs of at most 128 rows over K <= 1024
+ * when the WHOLE batch of the ViT call is that small (cuts x tokens <= 128: one or two cuts) -- the class-row GEMMs of a larger batch's
+ * last block stay on the two-pass split-K kernels; 2 = every shape below the wave-specialised kernel's threshold (A/B measurements),
+ * 0 = never (the shared-ring tile configurations 1 / 2 / 10 and their two-pass split-K).  The stand-alone entries (aph_gemm_f16 with
+ * tile_cfg 0) count as small batches.  Returns the previous value. */
 int aph_gemm_set_rs(int mode);
 /* Tile order of the wave-specialised GEMM inside an XCD's run: groups of g row panels, column tile by column tile inside a group
  * (0 = automatic: 4 for outputs of >= 12 column tiles, else 1 = n-fastest).  Returns the previous value. */

@@ -63,6 +63,10 @@ inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+  for (size_t r = 0; r < height; ++r) memcpy(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  return 0;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 typedef void* hipEvent_t;

@@ -149,3 +149,52 @@ def test_engine_ranks_gloo(world, cuts):
     d = np.abs(res[0][1] - eng.params.numpy())
     assert d.max() < 5e-3 and d.mean() < 5e-5, (d.max(), d.mean())
     assert np.allclose(res[0][2], want_losses, atol=1e-4)
+
+
+def test_skip_count_bookkeeping_across_reset_params():
+    """the guarded Adam counts overflowed (skipped) steps on the device; the host folds new skips into the bias-correction step
+    counter every GUARD_EVERY calls -- but only the skips of the CURRENT optimiser instance: reset_params (illustrip's per-frame fresh Adam)
+    snapshots the counter as a floor.  Faked here by writing the counter directly (CPU path of _check_overflow / reset_params):
+    a skip BEFORE a reset is not charged to the new frame, a skip AFTER it is, two resets inside one look-up window lose nothing."""
+    lib = _emu_lib()
+    eng, _, _ = _make_engine(lib)
+    E = eng.GUARD_EVERY
+    p0 = eng.params.clone()
+
+    def look(calls_multiple=1):
+        eng._calls = E * calls_multiple           # the counter is looked at when _calls is a multiple of GUARD_EVERY
+        eng._check_overflow()
+
+    scale0 = eng.loss_scale
+    # (1) one skip in frame A, then the reset: the new frame's optimiser must not pay for it
+    eng.guard[0] = 1
+    eng.reset_params(p0)
+    assert eng._state['step'][0] == 0 and eng._guard_floor == 1
+    eng._state['step'][0] = 3                     # three steps of frame B taken
+    look()
+    assert eng._state['step'][0] == 3 and eng._guard_seen == 1
+    assert eng.loss_scale == scale0 * 0.5 and eng._graphs is None       # (the overflow is still answered with a smaller loss scale)
+    # (2) a genuine skip of frame B right after the reset IS charged
+    eng.guard[0] = 2
+    look(2)
+    assert eng._state['step'][0] == 2 and eng._guard_seen == 2
+    # (3) two resets inside one window: skip in frame B (counter 3), reset -> frame C, skip in frame C (counter 4), reset -> frame D
+    eng.guard[0] = 3
+    eng.reset_params(p0)
+    eng.guard[0] = 4
+    eng.reset_params(p0)
+    assert eng._guard_floor == 4
+    eng._state['step'][0] = 5
+    look(3)
+    assert eng._state['step'][0] == 5 and eng._guard_seen == 4          # neither skip belongs to frame D
+    # (4) keep_optimizer_state (--smooth) keeps the step counter and the floor where they are
+    eng.guard[0] = 5
+    eng.reset_params(p0, keep_optimizer_state=True)
+    assert eng._guard_floor == 4 and eng._state['step'][0] == 5
+    look(4)
+    assert eng._state['step'][0] == 4
+    # the step counter never goes below zero
+    eng._state['step'][0] = 0
+    eng.guard[0] = 9
+    look(5)
+    assert eng._state['step'][0] == 0

@@ -11,6 +11,8 @@
 #   pmctable     SQ / LDS / MFMA / TA / TCC counter table of the C2 step (separate --pmc passes)
 #   ensemble     tools/loss_ensemble.py: both precision modes against the oracle ensemble of tests/golden/ensemble
 #   mr2          bench.py --gpus 2 on this one GPU through gloo (the N > 1 code path; RCCL refuses two ranks on one device)
+#   mr2torchrun  the same launched as the driver launches N > 1: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2
+#   mr2hang      the same with a test-only hang injected into the first rung of the supervised ladder
 #   py:<script> [args, '+' for spaces]   any python script, output to <tag>_<script name>.txt      (e.g. py:tools/exp/foo.py+--x+1)
 TAG=${1:?tag}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -80,6 +82,14 @@ for STAGE in "$@"; do
     mr2)
       APH_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs > $O/${TAG}_mr_gloo2.json 2> $O/${TAG}_mr_gloo2.err
       echo "rc $?"; cut -c1-600 $O/${TAG}_mr_gloo2.json; tail -3 $O/${TAG}_mr_gloo2.err ;;
+    mr2torchrun)
+      # the driver's own launch line for N > 1 (torchrun), two ranks on this one GPU through gloo: the supervisors run under torchrun's agent
+      APH_BENCH_BACKEND=gloo timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-roofline > $O/${TAG}_mr_torchrun2.json 2> $O/${TAG}_mr_torchrun2.err
+      echo "rc $?"; cut -c1-300 $O/${TAG}_mr_torchrun2.json; python -c "import json,sys; j=json.loads([l for l in open('$O/${TAG}_mr_torchrun2.json') if l.startswith('{')][-1]); print(j['config'].get('multi_rank_mode'), j['config'].get('multi_rank_ladder'), j['config'].get('params_identical_across_ranks'))"; tail -3 $O/${TAG}_mr_torchrun2.err ;;
+    mr2hang)
+      # the ladder with a test-only hang injected into the first rung: the line must come from the second rung
+      APH_BENCH_BACKEND=gloo APH_BENCH_INJECT_HANG=graph+rccl APH_BENCH_RUNG_BUDGET=75 timeout 500 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-roofline > $O/${TAG}_mr_gloo2_hang.json 2> $O/${TAG}_mr_gloo2_hang.err
+      echo "rc $?"; cut -c1-300 $O/${TAG}_mr_gloo2_hang.json; python -c "import json,sys; j=json.load(open('$O/${TAG}_mr_gloo2_hang.json')); print(j['config'].get('multi_rank_mode'), j['config'].get('multi_rank_ladder'))"; grep -c "INJECT_HANG" $O/${TAG}_mr_gloo2_hang.err ;;
     py:*)
       CMD=${STAGE#py:}; CMD=${CMD//+/ }; NAME=$(basename ${CMD%% *} .py)
       timeout 1500 python $CMD > $O/${TAG}_$NAME.txt 2>&1; echo "rc $?"; tail -40 $O/${TAG}_$NAME.txt | cut -c1-300 ;;

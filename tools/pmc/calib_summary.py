@@ -21,10 +21,11 @@ def per_kernel(d, counter):
 
 
 def label(k):
-    m = re.search(r'(rd_stride|rd|wr)_kernel(?:<([^>]*)>)?', k)
+    m = re.search(r'(rd_stride|rd|wr)_kernel(?:<(.*)>)?\s*\(', k) or re.search(r'(rd_stride|rd|wr)_kernel(?:<(.*)>)?', k)
     if not m:
         return None
-    t = {'unsigned short': '2B', 'float': '4B', 'float2': '8B', 'float4': '16B', 'HIP_vector_type<float, 2u>': '8B', 'HIP_vector_type<float, 4u>': '16B'}.get((m.group(2) or '').strip(), m.group(2))
+    arg = (m.group(2) or '').strip()
+    t = '2B' if 'short' in arg else '8B' if ('float2' in arg or ', 2u' in arg) else '16B' if ('float4' in arg or ', 4u' in arg) else '4B' if 'float' in arg else arg
     return {'rd': 'read_%s_per_lane' % t, 'wr': 'write_%s_per_lane' % t, 'rd_stride': 'read_4B_per_lane_stride2'}[m.group(1)]
 
 
