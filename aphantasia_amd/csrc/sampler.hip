@@ -1222,6 +1222,10 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
       else if (rbq == 2) APH_ADJ_ROWS(2, 3);
       else if (rbq == 3 && cpt == 1) APH_ADJ_ROWS(3, 1);
       else if (rbq == 4 && cpt == 1) APH_ADJ_ROWS(4, 1);
+      else if (rbq == 5 && cpt == 2) APH_ADJ_ROWS(5, 2);
+      else if (rbq == 5) APH_ADJ_ROWS(5, 3);
+      else if (rbq == 6 && cpt == 2) APH_ADJ_ROWS(6, 2);
+      else if (rbq >= 6) APH_ADJ_ROWS(6, 3);
       else
 #endif
       if (rbq == 3 && cpt == 2) APH_ADJ_ROWS(3, 2);

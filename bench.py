@@ -67,7 +67,8 @@ def parse():
     p.add_argument('--f16', action='store_true', help='(the default since round 6; accepted for old command lines) f16 operands on every ViT GEMM')
     p.add_argument('--reps', type=int, default=3, help='repetitions of the timed block of --steps steps (value = the median block)')
     p.add_argument('--vit-path', default=None, help='measurement switch: comma list of name=int pairs handed to the library\'s test hooks '
-                                                    '(rs: aph_gemm_set_rs, fused: aph_vit_set_fused_max_rows, ws: aph_gemm_set_ws_min_tiles)')
+                                                    '(rs: aph_gemm_set_rs, fused: aph_vit_set_fused_max_rows, ws: aph_gemm_set_ws_min_tiles, stream16: aph_vit_set_grad_stream_f16)')
+    p.add_argument('--grad-f16', default=None, type=int, choices=[0, 1], help='measurement switch: Engine(grad_f16=...) -- the patch gradient handed to the sampler adjoint as f16 (1) or f32 (0); default: the engine\'s')
     a = p.parse_args()
     if a.split and a.f16:
         p.error('--split and --f16 are mutually exclusive')
@@ -495,7 +496,7 @@ def main():
     from aphantasia_amd.clip import LOSS_SCALE
     if a.vit_path:                          # A/B runs only: the default line never passes this
         from aphantasia_amd import _ffi
-        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles')
+        hooks = dict(rs='aph_gemm_set_rs', fused='aph_vit_set_fused_max_rows', fattn='aph_vit_set_fused_attn', ws='aph_gemm_set_ws_min_tiles', stream16='aph_vit_set_grad_stream_f16')
         for kv in a.vit_path.split(','):
             k, v = kv.split('=')
             if not hasattr(_ffi.lib().cdll, hooks[k]):
@@ -547,6 +548,8 @@ def main():
         else:
             leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(dev).contiguous()
         kw['precise'] = not a.f16       # headline mode [r6]: f16 operands everywhere (the reference's own GPU dtype); --split = the opt-in split-precision forward
+        if a.grad_f16 is not None:
+            kw['grad_f16'] = bool(a.grad_f16)
         kw.update(extra)
         e1 = Engine(leaf, h, w, model, S_eff, [(target, -1.0)], **kw)
         e2 = Engine(leaf, h, w, model2, S_eff, [(target2, -1.0)], state=e1.state(), **kw) if dualmod is not None else None
@@ -646,10 +649,22 @@ def main():
             m_ = cfg['model']
             hilo_extra = 0.0 if (a.f16 or dualmod is not None or m_ not in F_T) else 2.0 * S * (F_T[m_] * 2 * 768 * 768 * 12 + F_P[m_] * 768 * F_KP[m_])     # (the lo half feeds the Q and K columns only)
             traffic, tsrc, stale, tmatch = (None, None, None, None)
-            if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1:
+            if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1 and a.f16:      # (the PMC passes run the default mode)
                 traffic, tsrc, stale, tmatch = pmc_traffic('r[0-9][0-9]_pmc_hbm_traffic*.json')
-            roof = dict(bound='mfma', kernel='aph::gemm_ws_kernel<*> / aph::gemm_f16_kernel<*> / aph::gemm_sk_kernel<*> (the ViT GEMM family)', achieved=achieved, peak=PEAK_TF,
-                        unit='TFLOP/s', frac=achieved / PEAK_TF, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
+            # both floors of the family's average launch: matrix-core time of its FLOPs at the datasheet peak, and HBM time of its MEASURED fabric
+            # traffic (PMC summary of this build) at the achievable bandwidth; `bound` names the binding (larger) one, `frac_of_binding_floor` is
+            # that floor over the measured launch time (on counter traffic the family sits below the ridge point)
+            avg_us = ms_t * 1e3 / n_t
+            floor_mfma_us = (fl_t / n_t) / (PEAK_TF * 1e12) * 1e6
+            floor_hbm_us = (traffic / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6) if traffic else None
+            binding = 'hbm' if (floor_hbm_us is not None and floor_hbm_us > floor_mfma_us) else 'mfma'
+            roof = dict(bound=binding, floors=dict(mfma_us=floor_mfma_us, hbm_us=floor_hbm_us, ridge_flop_per_byte=PEAK_TF * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9),
+                                                   arithmetic_intensity_flop_per_byte=(fl_t / n_t / traffic) if traffic else None,
+                                                   frac_of_binding_floor=(max(floor_mfma_us, floor_hbm_us or 0.0) / avg_us),
+                                                   note='`achieved` / `peak` / `frac` stay the MFMA figures (algorithmic FLOPs over measured time against 2.5 PF) so that rounds compare; '
+                                                        'on measured traffic the HBM floor is the higher of the two for this family'),
+                        kernel='aph::gemm_ws_kernel<*> / aph::gemm_f16_kernel<*> / aph::gemm_sk_kernel<*> (the ViT GEMM family)', achieved=achieved, peak=PEAK_TF,
+                        unit='TFLOP/s', frac=achieved / PEAK_TF, traffic=traffic, traffic_unit='bytes/launch (2*FETCH_SIZE + WRITE_SIZE; factors calibrated in profiles/r06_pmc_calibration.json)',
                         traffic_source=tsrc, traffic_stale=stale, traffic_match=tmatch, launches_per_step=n_t // nprof,
                         avg_launch_us=ms_t * 1e3 / n_t, flops_per_launch=fl_t / n_t, gemm_ms_per_step=ms_t / nprof,
                         executed_gemm_tflop_per_step=fl_t / nprof / 1e12,

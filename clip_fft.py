@@ -141,10 +141,11 @@ class FrameWriter:
     THREADS = 4        # (8 threads measured the same with-save rate: 153.6-154.0 vs 153.2 steps/s -- the encoders are not the limit)
     RING = 16          # slots of (device uint8 buffer, pinned host buffer); a slot is reused only after its writer released it (below)
 
-    def __init__(self, h, w, switch_interval=5e-4):
-        # The encoder threads spend most of their time inside PIL's C encoder (GIL released) but take the GIL for the Python around it; with the
-        # interpreter's default 5 ms switch interval the optimisation loop's thread can wait that long for it while the GPU idles.  0.5 ms keeps
-        # the loop's host work (0.2 ms per step) ahead of the 6 ms step.  None = leave the interpreter's setting alone.
+    def __init__(self, h, w, switch_interval=None):
+        # switch_interval: optionally lower the interpreter's GIL switch interval (default 5 ms) for the encoder threads' sake.  Measured in
+        # round 6 (tools/exp/save_ab.py, profiles/r06_save_ab.txt): 158.7 / 158.6 / 158.7 steps/s at 5 / 0.5 / 0.1 ms against 163.8 without
+        # saving -- the 3 % the per-step frame costs is device work (the contrast-1.1 synthesis, the uint8 conversion, the copy) and the
+        # loop's own enqueue calls, not GIL hand-over; left at the interpreter's setting.
         if switch_interval is not None and sys.getswitchinterval() > switch_interval:
             sys.setswitchinterval(switch_interval)
         self.q = queue.Queue(maxsize=8)

@@ -435,6 +435,19 @@ def test_vit_stress_weights(name):
     berr2 = (gx2 - x.grad).abs().max().item() / x.grad.abs().max().item()
     print('%s split-precision forward: enc rel %.2e (default %.2e) | input-grad rel %.2e (default %.2e)' % (name, ferr2, ferr, berr2, berr))
     assert ferr2 < 1.2 * ferr + 1e-5 and berr2 < 1.2 * berr + 1e-5, (ferr2, ferr, berr2, berr)
+    # [r6] the measurement switch aph_vit_set_grad_stream_f16 (the backward's residual-stream gradient kept in f16 only): the same single-step
+    # input gradient, max and rms error beside the fp32 stream's (DESIGN.md section 4 *Round 6*: what the LayerNorm-backward traffic cut costs)
+    from aphantasia_amd import _ffi
+    vit.forward(ops.patchify(x.detach().to(DEV).contiguous(), p), S)
+    rms = lambda g: ((g - x.grad).pow(2).sum() / x.grad.pow(2).sum()).sqrt().item()
+    prev = _ffi.lib().cdll.aph_vit_set_grad_stream_f16(1)
+    try:
+        gx3 = ops.unpatchify(vit.backward((genc * LOSS_SCALE).to(DEV).contiguous(), S, out_scale=1.0 / LOSS_SCALE), S, Rr, p).cpu()
+    finally:
+        _ffi.lib().cdll.aph_vit_set_grad_stream_f16(prev)
+    berr3 = (gx3 - x.grad).abs().max().item() / x.grad.abs().max().item()
+    print('%s f16-only gradient stream: input-grad max-rel %.2e (fp32 stream %.2e) | rms-rel %.2e (fp32 stream %.2e)' % (name, berr3, berr, rms(gx3), rms(gx)))
+    assert torch.isfinite(gx3).all() and berr3 < 2.0 * berr + 1e-5, (berr3, berr)
 
 
 def test_loss_curve_stress_weights():

@@ -44,7 +44,7 @@ base = timeit()
 print('%dx%d, %d cuts, patch %d: automatic shape %.1f us (tap tables + adjoint; experiments build: %s)' % (W, H, S, P, base, L.experiments), flush=True)
 res = []
 for nseg in (1, 2, 3, 4):
-    for rb in (4, 8, 9, 12, 16):
+    for rb in ((4, 8, 9, 12, 16) if H <= 1080 else (12, 16, 20, 24)):
         for cpt in (1, 2, 3):
             xw = ((W + nseg - 1) // nseg + 3) & ~3
             nthr = ((xw + cpt - 1) // cpt + 63) // 64 * 64
