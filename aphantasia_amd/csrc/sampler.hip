@@ -1192,7 +1192,7 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
     rb = rb < 4 ? 4 : (rb > 16 ? 16 : rb);
     if (ov.rb > 0) rb = ov.rb;
     int rbq = rb <= 12 ? 3 : 4;
-#ifdef APH_EXPERIMENTS
+#if defined(APH_EXPERIMENTS) && !defined(APH_EMU)
     if (ov.rb > 0) rbq = (rb + 3) / 4;
 #endif
     const int rbp = rbq * 4;
@@ -1213,7 +1213,7 @@ int launch_crop_adjoint(const void* gout, float gscale, const int* table, float*
     APH_ALLOW_SMEM((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), 150 * 1024);                                                                   \
     APH_LAUNCH((crop_adjoint_rows_kernel<OUT, RBQ, CPT>), rgrid, dim3(nthr), smem, st, gout, gscale, table, grgb, g, (const AdjEntry*)tab, maxcs, rb, nbc, dbg, xw, center_out); \
   } while (0)
-#ifdef APH_EXPERIMENTS       /* every (rows, columns per thread) shape, for the launch-shape sweep of tools/exp/crop_adjoint_sweep.py */
+#if defined(APH_EXPERIMENTS) && !defined(APH_EMU)       /* every (rows, columns per thread) shape, for the launch-shape sweep of tools/exp/crop_adjoint_sweep.py (GPU only: the interpreter build skips them) */
       if (rbq == 1 && cpt == 1) APH_ADJ_ROWS(1, 1);
       else if (rbq == 1 && cpt == 2) APH_ADJ_ROWS(1, 2);
       else if (rbq == 1) APH_ADJ_ROWS(1, 3);
