@@ -407,7 +407,7 @@ def launch_supervisors(a):
 
 def supervise(a, rank, world):
     """A rank process of a multi-rank launch (torchrun's or launch_supervisors'): it does no GPU work itself.  It runs the measurement in
-    a WORKER child, one rung of RUNGS at a time under a wall budget (APH_BENCH_RUNG_BUDGET seconds, default 240), and agrees with the other
+    a WORKER child, one rung of RUNGS at a time under a wall budget (APH_BENCH_RUNG_BUDGET seconds, default 180), and agrees with the other
     ranks' supervisors through files on whether the rung succeeded everywhere (aphantasia_amd.comm.ladder).  A worker that hangs in a
     capture or a collective is killed by its supervisor and the next rung starts on every rank; rank 0 prints the successful rung's JSON
     line with `config.multi_rank_mode` and the ladder's record -- or, if every rung failed, a line that says so.  (the
@@ -415,7 +415,7 @@ def supervise(a, rank, world):
     import tempfile
     from aphantasia_amd.comm import ladder
     sup = os.environ.get('APH_BENCH_SUP_DIR') or os.path.join(tempfile.gettempdir(), 'aph_bench_sup_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
-    budget = float(os.environ.get('APH_BENCH_RUNG_BUDGET', '240'))
+    budget = float(os.environ.get('APH_BENCH_RUNG_BUDGET', '180'))
     rungs = [r for r in os.environ.get('APH_BENCH_RUNGS', ','.join(RUNGS)).split(',') if r]
     for r in rungs:
         if r not in RUNGS:
@@ -469,7 +469,7 @@ def main():
     # kills the worker): a rank stuck in a collective leaves a stack behind, not just a timeout.  Cancelled after the timed section.
     wd = 0
     if world > 1:
-        wd = max(int(float(os.environ.get('APH_BENCH_RUNG_BUDGET', '240'))) - 15, 5)
+        wd = max(int(float(os.environ.get('APH_BENCH_RUNG_BUDGET', '180'))) - 15, 5)
         import faulthandler
         faulthandler.dump_traceback_later(wd, exit=False)
     # debugging aid for single-GPU boxes: APH_BENCH_BACKEND=gloo puts every rank on cuda:0 and reduces through the host
