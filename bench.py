@@ -483,6 +483,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # one node: the control plane stays on loopback (the container's hostname may not resolve)
         # ONE RCCL communicator per GPU: with the direct communicator (rungs 1 / 2) the control plane is a gloo group; only the
         # torch.distributed rung holds an nccl group (and then no direct communicator)
         if backend == 'nccl' and rung == 'eager+torch':

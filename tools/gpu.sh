@@ -12,6 +12,7 @@
 #   ensemble     tools/loss_ensemble.py: both precision modes against the oracle ensemble of tests/golden/ensemble
 #   mr2          bench.py --gpus 2 on this one GPU through gloo (the N > 1 code path; RCCL refuses two ranks on one device)
 #   mr2torchrun  the same launched as the driver launches N > 1: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2
+#   mr2fail      two RCCL ranks requested on this ONE-GPU box: every rung fails, the line must still appear (value null + ladder record)
 #   mr2hang      the same with a test-only hang injected into the first rung of the supervised ladder
 #   py:<script> [args, '+' for spaces]   any python script, output to <tag>_<script name>.txt      (e.g. py:tools/exp/foo.py+--x+1)
 TAG=${1:?tag}; shift
@@ -86,6 +87,11 @@ for STAGE in "$@"; do
       # the driver's own launch line for N > 1 (torchrun), two ranks on this one GPU through gloo: the supervisors run under torchrun's agent
       APH_BENCH_BACKEND=gloo timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-roofline > $O/${TAG}_mr_torchrun2.json 2> $O/${TAG}_mr_torchrun2.err
       echo "rc $?"; cut -c1-300 $O/${TAG}_mr_torchrun2.json; python -c "import json,sys; j=json.loads([l for l in open('$O/${TAG}_mr_torchrun2.json') if l.startswith('{')][-1]); print(j['config'].get('multi_rank_mode'), j['config'].get('multi_rank_ladder'), j['config'].get('params_identical_across_ranks'))"; tail -3 $O/${TAG}_mr_torchrun2.err ;;
+    mr2fail)
+      # every rung MUST fail here (two RCCL ranks requested on a one-GPU box: rank 1 has no device, RCCL refuses duplicates): the supervisors still print ONE line
+      # (value null + the ladder's record) and exit non-zero -- the "cannot end without a line" path on real hardware
+      APH_BENCH_RUNG_BUDGET=45 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-roofline > $O/${TAG}_mr_fail2.json 2> $O/${TAG}_mr_fail2.err
+      echo "rc $? (non-zero expected)"; grep "^{" $O/${TAG}_mr_fail2.json | cut -c1-1200 ;;
     mr2hang)
       # the ladder with a test-only hang injected into the first rung: the line must come from the second rung
       APH_BENCH_BACKEND=gloo APH_BENCH_INJECT_HANG=graph+rccl APH_BENCH_RUNG_BUDGET=75 timeout 500 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-roofline > $O/${TAG}_mr_gloo2_hang.json 2> $O/${TAG}_mr_gloo2_hang.err
