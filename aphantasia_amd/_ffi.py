@@ -32,7 +32,6 @@ _PROTOTYPES = {
     'aph_synth_plan_create': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     'aph_synth_plan_destroy': (c_int, [c_void_p]),
     'aph_synth_fft_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, POINTER(c_float), c_int, c_void_p, c_void_p, c_void_p]),
-    'aph_synth_frame_u8': (c_int, [c_void_p, c_void_p, c_float, POINTER(c_float), c_int, c_float, c_void_p, c_void_p]),
     'aph_synth_fft_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, POINTER(c_float), c_int, c_void_p, c_void_p]),
     'aph_irfft2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'aph_rfft2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

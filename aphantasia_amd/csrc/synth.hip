@@ -434,31 +434,6 @@ __global__ void rgb_fwd_kernel(const float* __restrict__ raw, const float* __res
   }
 }
 
-// [r6] The per-step FRAME straight from the forward's `raw` (clip_fft.py:297-306: image_f(contrast = a.contrast) -> checkout): the same
-// arithmetic as rgb_fwd_kernel at the frame's contrast followed by aph_rgb_to_u8 -- clip(rgb ** gamma * 255, 0, 255) truncated, HWC -- in
-// one pass over `raw` (11 MB read, 2.7 MB written at 720p) and without the second inverse FFT: the raw image of the parameters AFTER step i
-// is exactly what step i + 1's forward computes first.
-__global__ void frame_u8_kernel(const float* __restrict__ raw, const float* __restrict__ stats, float contrast, float fixed_div, ColorMat cc,
-                                int decorrelate, float gamma, unsigned char* __restrict__ out, size_t HW) {
-  const float k = fixed_div > 0.f ? contrast / fixed_div : contrast / stats[1];
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) {
-    const float n0 = raw[i] * k, n1 = raw[HW + i] * k, n2 = raw[2 * HW + i] * k;
-    float z[3] = {n0, n1, n2};
-    if (decorrelate) {
-      z[0] = n0 * cc.m[0] + n1 * cc.m[3] + n2 * cc.m[6];
-      z[1] = n0 * cc.m[1] + n1 * cc.m[4] + n2 * cc.m[7];
-      z[2] = n0 * cc.m[2] + n1 * cc.m[5] + n2 * cc.m[8];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float v = 1.0f / (1.0f + expf(-z[c]));
-      if (gamma != 1.0f) v = powf(v, gamma);
-      v = fminf(fmaxf(v * 255.0f, 0.0f), 255.0f);
-      out[i * 3 + c] = (unsigned char)v;
-    }
-  }
-}
-
 // dn[c] = sum_d cc[c][d] * drgb[d] * rgb[d] (1 - rgb[d]);  partial sums of dn * raw (fp64)
 __global__ void rgb_bwd_kernel(const float* __restrict__ drgb, const float* __restrict__ rgb,
                                const float* __restrict__ raw, ColorMat cc, int decorrelate, float gscale,
@@ -704,21 +679,6 @@ int aph_synth_fft_fwd(aph_synth_plan* p, const float* params, const float* scale
   APH_LAUNCH(rgb_fwd_kernel, dim3(kElemBlocks), dim3(256), 0, st, (const float*)raw, (const float*)p->stats, contrast, 0.f,
              to_cm(colcorr_t9), decorrelate, rgb, HW);
   return aph_check_launch("aph_synth_fft_fwd");
-  APH_CATCH
-}
-
-// [r6] uint8 frame [H,W,3] of the image whose `raw` the LAST aph_synth_fft_fwd on this plan produced (the plan keeps that call's std
-// statistics; stream order), at another contrast and with the saved frame's gamma: == aph_rgb_to_u8(rgb of aph_synth_fft_fwd(..., contrast))
-// bit for bit, without the transform.  C = 3 only.
-int aph_synth_frame_u8(aph_synth_plan* p, const float* raw, float contrast, const float* colcorr_t9, int decorrelate, float gamma,
-                       void* out_u8, void* stream_) {
-  APH_TRY
-  if (!p || !raw || !out_u8) return aph_fail(APH_ERR_ARG, "aph_synth_frame_u8: null argument");
-  if (p->C != 3) return aph_fail(APH_ERR_UNSUPPORTED, "aph_synth_frame_u8: %d channels (frames are RGB)", p->C);
-  const size_t HW = (size_t)p->H * p->W;
-  APH_LAUNCH(frame_u8_kernel, dim3(kElemBlocks), dim3(256), 0, (hipStream_t)stream_, raw, (const float*)p->stats, contrast, 0.f, to_cm(colcorr_t9),
-             decorrelate, gamma, (unsigned char*)out_u8, HW);
-  return aph_check_launch("aph_synth_frame_u8");
   APH_CATCH
 }
 

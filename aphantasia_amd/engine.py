@@ -95,7 +95,6 @@ class Engine:
         if world > 1 and (comm is None or not self.graph_allreduce):
             use_graph = False
         self.use_graph, self._graphs, self._calls, self._vit_handle = use_graph, None, 0, None
-        self._frame, self.frame_u8, self.frames_valid = None, None, False      # enable_frames()
         self.rgb_priors = (0.45, 0.17) if rgb_priors is True else rgb_priors       # illustrip.py:439-440 targets
         self.fixcontrast = bool(fixcontrast)
         self.sharp, self.expand = float(sharp), float(expand)       # clip_fft.py:269-270, :276-280
@@ -281,33 +280,12 @@ class Engine:
                    int(self.decorrelate), ops.ptr(self.rgb), st)
         return self.rgb
 
-    def enable_frames(self, contrast, gamma=1.0):
-        """[r6] Per-step frames without a second synthesis (clip_fft.py:297-306 saves image_f(contrast = a.contrast) after every step): from
-        now on every step ALSO writes `self.frame_u8` (uint8 [h,w,3]) = the frame of the parameters it STARTED from -- i.e. the frame the
-        reference saves after the PREVIOUS step -- straight from its forward's `raw` (aph_synth_frame_u8: one pass, a node of the step's
-        graph).  The caller saves step i's frame after step i + 1 and synthesises the last one explicitly.  FFT parameteriser only, and only
-        for steps without a `shift` (the saved frame never carries the --noise shift; such steps leave frame_u8 untouched and return
-        frames_valid False).  Returns False (nothing enabled) for the other parameterisers."""
-        if self.kind != 'fft':
-            return False
-        self._frame = (float(contrast), float(gamma))
-        if self.frame_u8 is None:
-            self.frame_u8 = torch.empty(self.h, self.w, 3, dtype=torch.uint8, device=self.dev)
-        self._graphs = None
-        self.frames_valid = False
-        return True
-
     def _enqueue_grad(self, shift):
         """forward + backward up to the parameter gradient: C-ABI calls only (capturable into a hipGraph)"""
         fixed_div = 3.3 if (self.fixcontrast and self.kind == 'pixel') else 0.0
         L, st = self.lib, ops._stream(self.params)
         Sl = self.S_loc
         self.synthesize(1.0, shift)
-        if self._frame is not None:
-            self.frames_valid = shift is None
-            if shift is None:
-                L.call('aph_synth_frame_u8', self.plan.handle, ops.ptr(self.raw), self._frame[0], _ffi.floats(self.cc), int(self.decorrelate), self._frame[1],
-                       ops.ptr(self.frame_u8), st)
         cc = _ffi.floats(self.cc)
         vit_scale, smp_scale, gmode = self._grad_modes()
         if Sl > 0:
@@ -575,7 +553,6 @@ class Engine:
         if use_graph and self._graphs is not None:
             self._graphs[0].replay()
             self.visual._generation += 1
-            self.frames_valid = self._frame is not None          # (replays only happen without a shift)
             return self.loss
         self._enqueue_grad(shift)
         if self._reduce:

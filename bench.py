@@ -575,16 +575,9 @@ def main():
                 return
             e = e2 if (e2 is not None and i >= dualmod and i % dualmod == 0) else e1          # list(range(steps))[dm::dm], clip_fft.py:135
             e.step()
-            if writer is not None:                                                             # clip_fft.py:297-306 (opt_step = 1), as this repo's clip_fft.py does it:
-                fname = os.path.join(tmpdir, '%04d.jpg' % i)
-                if fast_frames:               # [r6] the step also wrote the PREVIOUS step's frame from its forward's raw image: save that one now
-                    if pend[0] is not None:
-                        writer.put_u8(e.frame_u8, pend[0])
-                    pend[0] = fname
-                else:
-                    writer.put(e.synthesize(1.1).reshape(3, e.h, e.w), fname, 1.0)
-        pend = [None]
-        fast_frames = writer is not None and all(e_.enable_frames(1.1, 1.0) for e_ in (e1, e2) if e_ is not None)
+            if writer is not None:                                                             # clip_fft.py:297-306 (opt_step = 1)
+                img = e.synthesize(1.1)
+                writer.put(img.reshape(3, e.h, e.w), os.path.join(tmpdir, '%04d.jpg' % i), 1.0)
         for i in range(warmup):
             one(i)
         sync()
@@ -592,8 +585,6 @@ def main():
         for i in range(steps):
             one(i)
         if writer is not None:
-            if pend[0] is not None:           # the last frame has no next step: explicit synthesis
-                writer.put(e1.synthesize(1.1).reshape(3, e1.h, e1.w), pend[0], 1.0)
             writer.drain()                        # every frame of the timed region is on disk before the clock stops
         sync()
         dt = time.perf_counter() - t0
@@ -708,8 +699,8 @@ def main():
             writer.close()
             nfr = len([f for f in os.listdir(tmpdir) if f.endswith('.jpg')])
             legs['with_save'] = dict(value=a.steps / dts, unit='steps/s', ms_per_step=1e3 * dts / a.steps, frames_written=nfr,
-                                     note='per-step frame on (clip_fft.py:297-306, opt_step 1): the frame of step i comes out of step i + 1\'s forward (one fused pass raw -> uint8 in the step\'s graph, '
-                                          'Engine.enable_frames; the last one is synthesised explicitly) -> device ring -> pinned ring -> %d JPEG encoder threads; all frames on disk before the clock stops' % clip_fft.FrameWriter.THREADS)
+                                     note='per-step frame on (clip_fft.py:297-306, opt_step 1): image_f(contrast 1.1) -> uint8 on the device '
+                                          '-> pinned ring -> %d JPEG encoder threads; all frames on disk before the clock stops' % clip_fft.FrameWriter.THREADS)
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
 

@@ -200,28 +200,6 @@ class FrameWriter:
         self.copy_ev[k] = ev
         self.q.put((buf, ev, fname, k))
 
-    def put_u8(self, dev_u8, fname):
-        """dev_u8: device uint8 [H,W,3] the step just wrote (Engine.frame_u8: fixed buffer, rewritten by the next step).  One device-to-device
-        copy into the ring slot on the step's stream (a few microseconds: the next step may then overwrite the engine's buffer), the host copy
-        and the encoder as in put()."""
-        if self.dev is None:
-            self.dev = [torch.empty(self.h, self.w, 3, dtype=torch.uint8, device=dev_u8.device) for _ in range(self.RING)]
-            self.copy_stream = torch.cuda.Stream(device=dev_u8.device)
-        k = self.n % self.RING
-        self.n += 1
-        buf, dbuf = self.bufs[k], self.dev[k]
-        self.free[k].acquire()
-        if self.copy_ev[k] is not None:
-            torch.cuda.current_stream(dev_u8.device).wait_event(self.copy_ev[k])
-        dbuf.copy_(dev_u8, non_blocking=True)
-        done = torch.cuda.Event(); done.record()
-        self.copy_stream.wait_event(done)
-        with torch.cuda.stream(self.copy_stream):
-            buf.copy_(dbuf, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-        self.copy_ev[k] = ev
-        self.q.put((buf, ev, fname, k))
-
     def drain(self):
         """block until every frame handed to put() is on disk"""
         self.q.join()
@@ -379,12 +357,6 @@ def main(argv=None):
     writer = None if a.no_save else FrameWriter(h, w)
     # empirical tone mapping of the saved frames (clip_fft.py:300-303): **1.3 with --sync, **(1 + sharp/2) with --sharp
     gamma = 1.3 if (a.sync > 0 and a.in_img is not None) else (1 + a.sharp / 2. if a.sharp != 0 else 1.0)
-    # [r6] frames without a second synthesis: the image the reference saves after step i (image_f(contrast) of the updated parameters) is what
-    # step i + 1's forward computes first, so every step also writes the PREVIOUS step's frame (Engine.enable_frames: one fused pass in the step's
-    # graph) and the loop saves it one step late; the last frame, --noise runs (the saved frame carries no shift) and the DWT parameteriser take
-    # the explicit synthesis.
-    fast_frames = writer is not None and all(e_.enable_frames(a.contrast, gamma) for e_ in (eng, eng2) if e_ is not None)
-    pending = None                         # file name of the frame that the NEXT step's forward will produce
     t0 = time.time()
     for i in range(a.steps):
         e = eng2 if (eng2 is not None and i in dualmod_nums) else eng
@@ -392,24 +364,13 @@ def main(argv=None):
         shift = None
         if a.noise > 0 and a.dwt is not True:
             shift = (a.noise * torch.rand(1, 1, h, w // 2 + 1, 1)).reshape(h, w // 2 + 1).cuda().contiguous()
-        if pending is not None and not (fast_frames and shift is None):
-            # this step cannot produce the pending frame (it runs with a --noise shift): synthesise it now, before the parameters move on
-            writer.put(e.synthesize(a.contrast).reshape(3, h, w), pending, gamma)
-            pending = None
         e.step(lr=lr_cur, shift=shift)
-        if pending is not None:            # (fast path) e.frame_u8 = the frame of the parameters this step started from
-            assert e.frames_valid
-            writer.put_u8(e.frame_u8, pending)
-            pending = None
         if a.expand > 0:                                                                # clip_fft.py:276-280: prev_enc = out_enc.detach()
             for other in (eng, eng2):
                 if other is not None: other.set_prev_enc(e.enc)
         if i % a.opt_step == 0 and writer is not None:
-            fname = os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step))
-            if fast_frames and i + 1 < a.steps:
-                pending = fname                                                         # produced by step i + 1's forward
-            else:
-                writer.put(e.synthesize(a.contrast).reshape(3, h, w), fname, gamma)     # clip_fft.py:298-299 (last step / no fast path)
+            img = e.synthesize(a.contrast)                                              # clip_fft.py:298-299
+            writer.put(img.reshape(3, h, w), os.path.join(tempdir, '%04d.jpg' % (i // a.opt_step)), gamma)
         if (a.verbose or world > 1) and (i % 10 == 9 or i == a.steps - 1):
             gl = e.global_loss()               # (a collective when world > 1: every rank takes part, rank 0 prints)
             if a.verbose:

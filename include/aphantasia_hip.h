@@ -43,12 +43,6 @@ int aph_synth_plan_destroy(aph_synth_plan* plan);
  * irfft2 output before std-normalisation) and rgb [C,H,W] in (0,1). */
 int aph_synth_fft_fwd(aph_synth_plan* plan, const float* d_params, const float* d_scale, const float* d_shift,
                       float contrast, const float* colcorr_t9, int decorrelate, float* d_raw, float* d_rgb, void* stream);
-/* [r6] The per-step frame (clip_fft.py:297-306: image_f(contrast = a.contrast) -> utils.py:94-100 checkout) WITHOUT a second transform: the
- * uint8 [H,W,3] image of the `raw` the last aph_synth_fft_fwd on this plan produced (stream order: the plan keeps that call's statistics), at
- * the frame's contrast and gamma -- bit for bit aph_rgb_to_u8(rgb of aph_synth_fft_fwd(same parameters, contrast)).  The image of the
- * parameters after step i is what step i + 1's forward computes first, so a loop that saves every step needs no extra inverse FFT. */
-int aph_synth_frame_u8(aph_synth_plan* plan, const float* d_raw, float contrast, const float* colcorr_t9, int decorrelate, float gamma,
-                       void* d_out_u8, void* stream);
 /* adjoint: d_rgb_grad [C,H,W] (multiplied by gscale) -> d_grad_params [C,H,W/2+1,2].  Must follow the
  * aph_synth_fft_fwd that produced rgb/raw (the plan keeps mean/std). */
 int aph_synth_fft_bwd(aph_synth_plan* plan, const float* d_rgb_grad, float gscale, const float* d_rgb, const float* d_raw,

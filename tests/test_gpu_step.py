@@ -524,51 +524,3 @@ def test_frame_writer_ring_reuse_keeps_every_frame(tmp_path):
     for i in range(n):
         back = np.asarray(Image.open(os.path.join(tmp_path, '%03d.png' % i)))
         assert back.shape == (h, w, 3) and int(back.min()) == i and int(back.max()) == i, i
-
-
-def test_frames_from_the_next_steps_forward_equal_explicit_synthesis(tmp_path):
-    """[r6] Engine.enable_frames: step i + 1 also writes, from its forward's raw image, the uint8 frame the reference saves AFTER step i
-    (clip_fft.py:297-306: image_f(contrast) of the updated parameters -> checkout).  Two identical engines: one saves every frame through the
-    explicit path (synthesize(contrast) + aph_rgb_to_u8), the other takes Engine.frame_u8 one step late (eager steps, then hipGraph
-    replays; gamma 1 and 1.15; a step WITH a --noise shift in the middle, which must not produce a frame) -- every frame bit-identical, and
-    the two runs' parameters too (the extra kernel writes nothing the step reads)."""
-    from aphantasia_amd import clip as aclip, transforms
-    from aphantasia_amd.engine import Engine
-    h, w, S, steps = 96, 160, 6, 9
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        model, _ = aclip.load('ViT-B/32', seed=1, max_batch=S)
-    target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
-    for contrast, gamma in ((1.1, 1.0), (0.9, 1.15)):
-        def make():
-            seed_all(0)
-            p = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).to(DEV).contiguous()
-            return Engine(p, h, w, model, S, [(target, -1.0)], sim='mix', transform=transforms.transforms_fast, macro=0.4)
-        ref, fast = make(), make()
-        assert fast.enable_frames(contrast, gamma) is True
-        u8 = torch.empty(h, w, 3, dtype=torch.uint8, device=DEV)
-        want, got = [], []
-        shifts = {4: (0.05 * torch.rand(h, w // 2 + 1, generator=torch.Generator().manual_seed(7))).to(DEV).contiguous()}
-        for i in range(steps):
-            seed_all(100 + i)
-            ref.step(shift=shifts.get(i))
-            img = ref.synthesize(contrast)
-            _ffi.lib().call('aph_rgb_to_u8', ops.ptr(img), h, w, float(gamma), ops.ptr(u8), ops._stream(img))
-            want.append(u8.cpu().clone())
-            seed_all(100 + i)
-            fast.step(shift=shifts.get(i))
-            if i > 0:
-                if i in shifts:
-                    assert not fast.frames_valid                  # a step with a shift produces no frame (the saved image carries none)
-                    got.append(None)
-                else:
-                    assert fast.frames_valid
-                    got.append(fast.frame_u8.cpu().clone())       # the frame of step i - 1
-        assert fast._graphs is not None                           # the later steps were replays: the frame kernel is a node of the graph
-        for i, g in enumerate(got):
-            if g is not None:
-                assert torch.equal(g, want[i]), (contrast, gamma, i, (g.int() - want[i].int()).abs().max().item())
-        assert torch.equal(ref.params, fast.params)
-    # the other parameterisers decline (the CLI then keeps the explicit synthesis)
-    px = Engine((0.3 * torch.randn(1, 3, h, w)).to(DEV).contiguous(), h, w, model, S, [(target, -1.0)], sim='mix', transform=transforms.normalize(), param_kind='pixel')
-    assert px.enable_frames(1.1) is False

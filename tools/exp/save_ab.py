@@ -15,7 +15,7 @@ with warnings.catch_warnings():
 target = torch.randn(1, 512, generator=torch.Generator().manual_seed(2))
 
 
-def run(save, interval, fast=False):
+def run(save, interval):
     torch.manual_seed(0); np.random.seed(0)
     sys.setswitchinterval(0.005)
     leaf = (0.01 * torch.randn(1, 3, h, w // 2 + 1, 2)).cuda().contiguous()
@@ -27,23 +27,10 @@ def run(save, interval, fast=False):
             eng.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if fast:
-            assert eng.enable_frames(1.1, 1.0)
-            eng.step()
-        pend = None
         for i in range(steps):
             eng.step()
-            fname = os.path.join(tmp, '%04d.jpg' % i)
-            if writer is not None and fast:          # [r6] the frame of step i - 1 out of step i's forward (Engine.enable_frames)
-                if pend is not None:
-                    writer.put_u8(eng.frame_u8, pend)
-                pend = fname
-            elif writer is not None:
-                writer.put(eng.synthesize(1.1).reshape(3, h, w), fname, 1.0)
-        if pend is not None:
-            writer.put(eng.synthesize(1.1).reshape(3, h, w), pend, 1.0)
-        torch.cuda.synchronize()
-        t_dev = time.perf_counter() - t0                  # the device is through; what follows is the encoders' tail
+            if writer is not None:
+                writer.put(eng.synthesize(1.1).reshape(3, h, w), os.path.join(tmp, '%04d.jpg' % i), 1.0)
         if writer is not None:
             writer.drain()
         torch.cuda.synchronize()
@@ -52,12 +39,8 @@ def run(save, interval, fast=False):
         if writer is not None:
             writer.close()
         shutil.rmtree(tmp, ignore_errors=True)
-    return steps / dt, steps / t_dev
+    return steps / dt
 
 
 for rep in range(2):
-    a, b, c = run(False, None), run(True, None), run(True, None, fast=True)
-    print('%d steps: no save %.1f | explicit synthesis per frame %.1f (device done: %.1f) | frame from the next step\'s forward %.1f (device done: %.1f) steps/s' % (steps, a[0], b[0], b[1], c[0], c[1]), flush=True)
-if len(sys.argv) <= 2:
-    for rep in range(2):
-        print('GIL switch interval 5 / 0.5 / 0.1 ms (explicit path): %.1f / %.1f / %.1f steps/s' % (run(True, None)[0], run(True, 5e-4)[0], run(True, 1e-4)[0]), flush=True)
+    print('no save %.1f   save, 5 ms switch interval %.1f   save, 0.5 ms %.1f   save, 0.1 ms %.1f  steps/s' % (run(False, None), run(True, None), run(True, 5e-4), run(True, 1e-4)), flush=True)
