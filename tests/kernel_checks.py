@@ -470,9 +470,21 @@ def check_vit(lib, dev, cfg=TINY, S=3, fwd_tol=3e-3, bwd_tol=2e-2, check_fuse=Tr
     assert berr < bwd_tol, berr
     if not check_fuse or hilo:
         return ferr, berr
+    # [r6] the f16-only gradient stream (aph_vit_set_grad_stream_f16: every LayerNorm backward takes its residual from the f16 copy its
+    # predecessor wrote and writes no fp32 stream): the same input gradient to within the f16 rounding of the stream, and switching it off
+    # again restores the fp32-stream bits
+    L = lib if lib is not None else _ffi.lib()
+    prev16 = L.call('aph_vit_set_grad_stream_f16', 1)
+    try:
+        gp16 = vit.backward((genc * LS).to(dev).contiguous(), S, out_scale=1.0 / LS).clone()
+    finally:
+        L.call('aph_vit_set_grad_stream_f16', prev16)
+    gx16 = ops.unpatchify(gp16, S, Rr, p, lib=lib)
+    berr16 = (gx16.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert berr16 < 2 * bwd_tol and not torch.equal(gp16, gp), (berr16, berr)
+    assert torch.equal(vit.backward((genc * LS).to(dev).contiguous(), S, out_scale=1.0 / LS), gp)
     # the fused LayerNorm pairs of the first block (and the unfilled fp32 gradient stream) against the separate kernels: the same
     # arithmetic on the same values, so the results are equal bit for bit
-    L = lib if lib is not None else _ffi.lib()
     enc1, gp1 = enc.clone(), gp.clone()
     prev = L.call('aph_vit_set_fuse_ln', 0)
     try:

@@ -7,6 +7,8 @@ import os
 import sys
 
 import pytest
+import numpy as np
+import torch
 
 from aphantasia_amd import _ffi
 import kernel_checks as K
@@ -148,6 +150,38 @@ def test_vit_through_the_wave_specialised_gemm(emu):
 
 def test_vit(emu):
     K.check_vit(emu, 'cpu')
+
+
+def test_vit_split_precision_needs_enable_hilo(emu):
+    """[r6] the K-repeated weight copies of the split-precision forward live in an arena of their own that only aph_vit_enable_hilo allocates:
+    aph_vit_forward_hilo on a fresh handle is refused with a message that names the call; enabling is idempotent, survives a weight reload
+    (the copies are refreshed), and the default forward never needs it"""
+    import ctypes
+    from aphantasia_amd import ops
+    from aphantasia_amd.weights import synthetic_visual_weights
+    cfg = K.TINY
+    w = synthetic_visual_weights(cfg, 3)
+    vit = ops.VitHandle(cfg, w, max_batch=2, lib=emu)
+    base_bytes = vit.workspace_bytes()
+    x = torch.randn(2, 3, cfg['input_resolution'], cfg['input_resolution'], generator=torch.Generator().manual_seed(1))
+    p = cfg['patch_size']
+    hilo = ops.patchify(x, p, lib=emu, hilo=True)
+    out = torch.empty(2, cfg['output_dim'])
+    rc = emu.cdll.aph_vit_forward_hilo(vit.handle, ops.ptr(hilo), 2, ops.ptr(out), None)
+    assert rc < 0 and 'aph_vit_enable_hilo' in emu.last_error()
+    enc_plain = vit.forward(ops.patchify(x, p, lib=emu), 2).clone()                 # the default path works on the bare handle
+    vit.enable_hilo()
+    vit.enable_hilo()                                                                # idempotent
+    assert vit.workspace_bytes() > base_bytes
+    enc = vit.forward(hilo, 2, hilo=True).clone()
+    assert (enc - enc_plain).abs().max().item() < 3e-3 * enc_plain.abs().max().item()
+    # a weight reload after enabling refreshes the copies: scaling in_proj by 0 on every layer changes the split forward exactly as the plain one
+    for li in range(cfg['layers']):
+        k = 'transformer.resblocks.%d.attn.in_proj_weight' % li
+        a = np.ascontiguousarray((w[k] * 0.5).numpy())
+        emu.call('aph_vit_set_weight', vit.handle, k.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size)
+    enc2, enc2_plain = vit.forward(hilo, 2, hilo=True).clone(), vit.forward(ops.patchify(x, p, lib=emu), 2).clone()
+    assert not torch.equal(enc2, enc) and (enc2 - enc2_plain).abs().max().item() < 3e-3 * enc2_plain.abs().max().item()
 
 
 @pytest.mark.parametrize('fattn', [0, 2])
