@@ -103,6 +103,7 @@ _EXPERIMENT_PROTOTYPES = {
     'aph_vit_set_fused_attn': (c_int, [c_int]),
     'aph_gemm_pack_frag': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'aph_attn_set_bwd_one': (c_int, [c_int]),
+    'aph_attn_set_ablate': (c_int, [c_int]),
 }
 
 

@@ -316,10 +316,18 @@ inline int attn_bwd_wgs(int items) {
   return items < w ? items : w;
 #endif
 }
+#ifdef APH_EXPERIMENTS
+int g_attn_ablate = 0;       // aph_attn_set_ablate: measurement variants of the T <= 56 backward (WRONG results)
+#endif
 void launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   const int T = a.T, items = a.S * a.heads;
   if (T <= AT_T)       // (the split dQ / dKdV kernels with NB = 1 were measured slower here: 7.62 vs 7.35 ms per C2 step)
   {
+#ifdef APH_EXPERIMENTS
+    if (T <= AT_RB && g_attn_ablate == 1) { APH_LAUNCH((attn_bwd_mfma_kernel<AT_RB, 1>), dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items); return; }
+    if (T <= AT_RB && g_attn_ablate == 2) { APH_LAUNCH((attn_bwd_mfma_kernel<AT_RB, 2>), dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items); return; }
+    if (T <= AT_RB && g_attn_ablate == 3) { APH_LAUNCH((attn_bwd_mfma_kernel<AT_RB, 3>), dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items); return; }
+#endif
     if (T <= AT_RB)
       APH_LAUNCH(attn_bwd_mfma_kernel<AT_RB>, dim3(attn_bwd_wgs(items)), dim3(256), 0, st, a.qkv, a.datt, (const float*)a.lse, a.dqkv, T, a.heads, items);
     else
@@ -657,6 +665,12 @@ int aph_vit_set_grad_stream_f16(int on) {
 }
 
 #ifdef APH_EXPERIMENTS
+// measurement variants of the T <= 56 attention backward (WRONG results): 0 = the kernel, 1 = no products (zeros stored), 2 = no stores, 3 = loads + staging only
+int aph_attn_set_ablate(int mode) {
+  const int prev = g_attn_ablate;
+  g_attn_ablate = mode < 0 || mode > 3 ? 0 : mode;
+  return prev;
+}
 // largest batch (token rows S * T) that runs the fused block kernels of vit_block.h (0 = never).  Returns the previous value.
 int aph_vit_set_fused_max_rows(int rows) {
   const int prev = g_fused_max_rows;

@@ -22,6 +22,11 @@ __device__ __forceinline__ int slot_of(int n) { return ((n >> 5) << 5) + (((n >>
 
 // [64 rows][64 halfs] tile, 16-byte chunks XOR-swizzled exactly like the GEMM tiles (conflict-free b128 reads)
 __device__ __forceinline__ int at_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// [r6] the TRANSPOSED images (V^T, K^T, Q^T, dO^T: [64 d][64 slots]) swizzle by row >> 2 instead: since the output products read their rows in
+// the order d = 4 c16 + nt (whole output rows per store, at_fwd_tiles), sixteen lanes hit rows 4 apart -- (row >> 1) & 7 would take only four
+// values there (4-way bank conflicts: the blocked forward went from 46 to 66 us), (row >> 2) & 7 takes eight (2-way, what consecutive rows
+// had under at_off)
+__device__ __forceinline__ int at_off_t(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 7)) << 3); }
 
 // Stage one 64x64 tile (T valid rows of 64 halfs, row stride ld in global) into LDS as a swizzled row-major image
 // and/or as its transposed slot-permuted image.  64 work items cover the tile: item = (d-chunk c, slot-chunk sc),
@@ -41,7 +46,8 @@ __device__ __forceinline__ void at_stage_load(const half_t* __restrict__ src, in
     rows[i] = n < T ? v : z;
   }
 }
-__device__ __forceinline__ void at_stage_store(const half8 (&rows)[8], int item, half_t* rowmajor, half_t* transposed, int row_limit = 64) {
+__device__ __forceinline__ void at_stage_store(const half8 (&rows)[8], int item, half_t* rowmajor, half_t* transposed, int row_limit = 64,
+                                               bool tswz = true) {      // tswz: the transposed image uses at_off_t (false: at_off, for readers that take its rows in natural order)
   const int c = item >> 3, sc = item & 7;
   const int nbase = ((sc >> 2) << 5) + ((sc & 3) << 2);
   if (rowmajor) {
@@ -57,19 +63,22 @@ __device__ __forceinline__ void at_stage_store(const half8 (&rows)[8], int item,
       half8 col;
 #pragma unroll
       for (int i = 0; i < 8; ++i) col[i] = rows[i][e];
-      *reinterpret_cast<half8*>(transposed + at_off(c * 8 + e, sc)) = col;
+      *reinterpret_cast<half8*>(transposed + (tswz ? at_off_t(c * 8 + e, sc) : at_off(c * 8 + e, sc))) = col;
     }
   }
 }
 __device__ __forceinline__ void at_stage_item(const half_t* __restrict__ src, int ld, int T, int item, half_t* rowmajor,
-                                              half_t* transposed, int row_limit = 64) {
+                                              half_t* transposed, int row_limit = 64, bool tswz = true) {
   half8 rows[8];
   at_stage_load(src, ld, T, item, rows);
-  at_stage_store(rows, item, rowmajor, transposed, row_limit);
+  at_stage_store(rows, item, rowmajor, transposed, row_limit, tswz);
 }
 
 __device__ __forceinline__ half8 at_frag(const half_t* tile, int row, int chunk) {
   return *reinterpret_cast<const half8*>(tile + at_off(row, chunk));
+}
+__device__ __forceinline__ half8 at_frag_t(const half_t* tile, int row, int chunk) {      // fragment of a transposed image (at_off_t)
+  return *reinterpret_cast<const half8*>(tile + at_off_t(row, chunk));
 }
 // fragment of a row-major tile that only holds rows < limit (the rest are zero by construction)
 __device__ __forceinline__ half8 at_frag_rows(const half_t* tile, int row, int chunk, int limit) {
@@ -161,12 +170,24 @@ __device__ __forceinline__ void at_fwd_tiles(const half_t* Qs, const half_t* Ks,
   const half8 p0 = pack8(st[0], st[1]), p1 = pack8(st[2], st[3]);
   const float inv = 1.0f / l;
   const int i = it * 16 + c16;
+  // [r6] O = P V with the PROBABILITIES as the A fragment (rows = queries) and the V image's rows taken in the order d = 4 c16 + nt as B:
+  // lane (c16, g) then holds, for each of its four queries g*4 + r, the four CONSECUTIVE columns 4 c16 .. 4 c16 + 3, and the sixteen lanes
+  // c16 = 0..15 hold that row's 64 columns in order -- a store instruction writes four whole 128-byte rows from adjacent lanes (the same
+  // output layout the wave-specialised GEMM's epilogue uses).  The form it replaces (V^T as A: one query per lane, 4 of its columns per
+  // product) wrote 32 bytes of sixteen different rows per instruction; tools/exp/attn_ablate.py: the backward's partial-line stores cost
+  // 13.5 us of its 27.8.  Same products, same k order: the sums are unchanged.
+  f32x4 o[4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, g), p0, o);
-    o = mfma_16x16x32_f16(at_frag(Vt, dt * 16 + c16, 4 + g), p1, o);
-    if (i < T) store_h4(att_row0 + (size_t)i * D + dt * 16 + g * 4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  for (int nt = 0; nt < 4; ++nt) {
+    o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o[nt] = mfma_16x16x32_f16(p0, at_frag_t(Vt, 4 * c16 + nt, g), o[nt]);
+    o[nt] = mfma_16x16x32_f16(p1, at_frag_t(Vt, 4 * c16 + nt, 4 + g), o[nt]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = it * 16 + g * 4 + r;
+    const float iq = __shfl(inv, g * 4 + r);          // 1 / l of query q lives in the lanes with c16 = g*4 + r
+    if (q < T) store_h4(att_row0 + (size_t)q * D + 4 * c16, o[0][r] * iq, o[1][r] * iq, o[2][r] * iq, o[3][r] * iq);
   }
   if (g == 0 && i < T) lse_row0[i] = mx * 0.125f + __logf(l);
 }
@@ -202,7 +223,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const half_t* __rest
 // at 170 VGPRs under a 168-register bound the compiler spilled one address pair, and its reload -- `scratch_load` + `s_waitcnt vmcnt(0)`,
 // vmcnt being one in-order counter -- sat right behind the prefetch loads of the next item: every wave waited for its prefetch to LAND
 // before starting the products the prefetch was meant to hide behind (found in the ISA; round 2's 35.7 -> 30.7 us was what survived).
-template <int RB>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
+// ABL (measurement only, -DAPH_EXPERIMENTS builds, tools/exp/attn_ablate.py -- WRONG results): 1 = no products (the stores write zeros: loads +
+// staging + stores, the memory skeleton), 2 = no stores (loads + staging + products), 3 = loads + staging only
+template <int RB, int ABL = 0>            // rows kept per row-major LDS tile: 56 (T <= 56: 3 workgroups per CU) or 64
 __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ datt,
                                                            const float* __restrict__ lse, half_t* __restrict__ dqkv, int T, int heads, int items) {
   constexpr int RT = RB * 64;                    // halfs per row-major tile
@@ -241,6 +264,20 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
     const int next = item + gridDim.x;
     if (next < items) fetch(next);               // in flight during the products and stores below
     half_t* dbase = dqkv + (size_t)s * T * ld + h * 64;
+    if (ABL & 1) {          // ablation: the three output tiles as zeros (same store pattern), or nothing at all
+      if (active && !(ABL & 2)) {
+        const int i = w * 16 + c16;
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            if (i < T) store_h4(dbase + (size_t)i * ld + part * D + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
+      }
+      if (next >= items) break;
+      item = next;
+      __syncthreads();
+      continue;
+    }
     if (active) {
       // ---- phase A: wave = query tile.  S^T = K Q^T, dP^T = V dO^T (lane: query i, keys jt*16 + g*4 + r)
       const int it = w, i = it * 16 + c16;
@@ -274,12 +311,19 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[jt][r] = at_ds(st[jt][r], dp[jt][r], Di);      // dS^T
       const half8 d0 = pack8(st[0], st[1]), d1 = pack8(st[2], st[3]);
+      // [r6] dQ = dS K with dS as the A fragment and K^T's rows in the order d = 4 c16 + nt as B: whole 128-byte rows per store (at_fwd_tiles)
+      f32x4 o[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, g), d0, o);
-        o = mfma_16x16x32_f16(at_frag(Kt, dt * 16 + c16, 4 + g), d1, o);
-        if (i < T) store_h4(dbase + (size_t)i * ld + dt * 16 + g * 4, o[0], o[1], o[2], o[3]);
+      for (int nt = 0; nt < 4; ++nt) {
+        o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o[nt] = mfma_16x16x32_f16(d0, at_frag_t(Kt, 4 * c16 + nt, g), o[nt]);
+        o[nt] = mfma_16x16x32_f16(d1, at_frag_t(Kt, 4 * c16 + nt, 4 + g), o[nt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = it * 16 + g * 4 + r;
+        if (!(ABL & 2) && q < T) store_h4(dbase + (size_t)q * ld + 4 * c16, o[0][r], o[1][r], o[2][r], o[3][r]);
+        if ((ABL & 2) && o[0][r] == 1.2345e33f) store_h4(dbase, o[0][r], o[1][r], o[2][r], o[3][r]);        // (keeps the products alive)
       }
     } else if (lane < 16) {
       Ds[w * 16 + lane] = 0.f;                     // query tiles past T (their dO rows are zero)
@@ -315,17 +359,26 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
       }
       const half8 p0 = pack8(pp[0], pp[1]), p1 = pack8(pp[2], pp[3]);
       const half8 s0 = pack8(sq[0], sq[1]), s1 = pack8(sq[2], sq[3]);
+      // [r6] dV = P^T dO, dK = dS^T Q with P^T / dS^T as the A fragments (rows = keys) and the dO^T / Q^T images' rows in the order d = 4 c16 + nt
+      // as B: lane (c16, g) holds columns 4 c16 .. 4 c16 + 3 of keys g*4 + r -- whole rows per store instruction (at_fwd_tiles)
+      f32x4 ov[4], ok[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
-        ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, g), p0, ov);
-        ov = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, 4 + g), p1, ov);
-        ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, g), s0, ok);
-        ok = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, 4 + g), s1, ok);
-        if (j < T) {
-          store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[0], ok[1], ok[2], ok[3]);
-          store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[0], ov[1], ov[2], ov[3]);
+      for (int nt = 0; nt < 4; ++nt) {
+        ov[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ok[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ov[nt] = mfma_16x16x32_f16(p0, at_frag_t(Ot, 4 * c16 + nt, g), ov[nt]);
+        ov[nt] = mfma_16x16x32_f16(p1, at_frag_t(Ot, 4 * c16 + nt, 4 + g), ov[nt]);
+        ok[nt] = mfma_16x16x32_f16(s0, at_frag_t(Qt, 4 * c16 + nt, g), ok[nt]);
+        ok[nt] = mfma_16x16x32_f16(s1, at_frag_t(Qt, 4 * c16 + nt, 4 + g), ok[nt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = jt * 16 + g * 4 + r;
+        if (!(ABL & 2) && kj < T) {
+          store_h4(dbase + (size_t)kj * ld + D + 4 * c16, ok[0][r], ok[1][r], ok[2][r], ok[3][r]);
+          store_h4(dbase + (size_t)kj * ld + 2 * D + 4 * c16, ov[0][r], ov[1][r], ov[2][r], ov[3][r]);
         }
+        if ((ABL & 2) && ok[0][r] + ov[0][r] == 1.2345e33f) store_h4(dbase, ok[0][r], ok[1][r], ov[2][r], ov[3][r]);
       }
     }
     if (next >= items) break;
@@ -349,10 +402,10 @@ __global__ __launch_bounds__(256, RB == 56 ? 3 : 2) void attn_bwd_mfma_kernel(co
 // scale, mask, max, subtract, exp, sum, convert: ~15 VALU slots per score, 2.6 k clocks per query tile next to 0.9 k of MFMA -- is what a
 // workgroup spends its time on; the static item split only added a 5-against-4.45 rounding.  git show <this commit>~1 has the code.)
 template <int NB>
-__device__ __forceinline__ void atg_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed, int idx) {
+__device__ __forceinline__ void atg_stage(const half_t* __restrict__ src, int ld, int T, half_t* rowmajor, half_t* transposed, int idx, bool tswz = true) {
   const int blk = idx >> 6, item = idx & 63;
   at_stage_item(src + (size_t)blk * 64 * ld, ld, T - blk * 64, item, rowmajor ? rowmajor + blk * 4096 : nullptr,
-                transposed ? transposed + blk * 4096 : nullptr);
+                transposed ? transposed + blk * 4096 : nullptr, 64, tswz);
 }
 
 __device__ __forceinline__ half8 ld_frag_global(const half_t* __restrict__ p, bool ok) {
@@ -371,7 +424,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __re
   const half_t* base = qkv + (size_t)s * T * ld + h * 64;
   for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
     if (idx < NB * 64) atg_stage<NB>(base + D, ld, T, Ks, nullptr, idx);
-    else atg_stage<NB>(base + 2 * D, ld, T, nullptr, Vt, idx - NB * 64);
+    else atg_stage<NB>(base + 2 * D, ld, T, nullptr, Vt, idx - NB * 64, false);      // (this kernel reads V^T's rows in natural order: at_off)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -422,6 +475,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_g_kernel(const half_t* __re
         for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_16x16x32_f16(at_frag(Vt + (kb >> 1) * 4096, dt * 16 + c16, (kb & 1) * 4 + g), pf, o[dt]);
       }
     }
+    // ([r6] the whole-row store form of at_fwd_tiles -- probabilities as the A fragment, V^T rows in the order 4 c16 + dt -- was measured on this
+    //  kernel too: 46 -> 65 us at C4's shape, with either LDS swizzle; the 15 MB of `att` are 13 % of this kernel's traffic and its time is the
+    //  softmax arithmetic (see above), so the one-query-per-lane store stays here.)
     if (i < T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -448,7 +504,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_g_kernel(const half_t* __rest
   const half_t* dob = datt + (size_t)s * T * D + h * 64;
   const half_t* ob = att + (size_t)s * T * D + h * 64;
   for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
-    if (idx < NB * 64) atg_stage<NB>(base + D, ld, T, Ks, Kt, idx);
+    if (idx < NB * 64) atg_stage<NB>(base + D, ld, T, Ks, Kt, idx, false);      // (natural row order below: at_off)
     else atg_stage<NB>(base + 2 * D, ld, T, Vs, nullptr, idx - NB * 64);
   }
   __syncthreads();
@@ -519,8 +575,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_g_kernel(const half_t* __res
   const half_t* base = qkv + (size_t)s * T * ld + h * 64;
   const half_t* dob = datt + (size_t)s * T * D + h * 64;
   for (int idx = threadIdx.x; idx < 2 * NB * 64; idx += 512) {
-    if (idx < NB * 64) atg_stage<NB>(base, ld, T, Qs, Qt, idx);
-    else atg_stage<NB>(dob, D, T, Os, Ot, idx - NB * 64);
+    if (idx < NB * 64) atg_stage<NB>(base, ld, T, Qs, Qt, idx, false);      // (natural row order below: at_off)
+    else atg_stage<NB>(dob, D, T, Os, Ot, idx - NB * 64, false);
   }
   for (int r = threadIdx.x; r < NB * 64; r += 512) {
     Ls[r] = r < T ? lse[((size_t)s * heads + h) * T + r] * kLog2e : 0.f;
@@ -690,9 +746,9 @@ __global__ __launch_bounds__(512) void attn_bwd_one_g_kernel(const half_t* __res
             }
             const half8 pf = pack8(pp[0], pp[1]), sf = pack8(sq[0], sq[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-              ov[jj][dt] = mfma_16x16x32_f16(at_frag(Ot, dt * 16 + c16, qb * 4 + g), pf, ov[jj][dt]);
-              ok[jj][dt] = mfma_16x16x32_f16(at_frag(Qt, dt * 16 + c16, qb * 4 + g), sf, ok[jj][dt]);
+            for (int dt = 0; dt < 4; ++dt) {      // [r6] P^T / dS^T as A (rows = keys), the dO^T / Q^T rows in the order d = 4 c16 + dt as B: whole dK / dV rows per store (at_fwd_tiles)
+              ov[jj][dt] = mfma_16x16x32_f16(pf, at_frag_t(Ot, 4 * c16 + dt, qb * 4 + g), ov[jj][dt]);
+              ok[jj][dt] = mfma_16x16x32_f16(sf, at_frag_t(Qt, 4 * c16 + dt, qb * 4 + g), ok[jj][dt]);
             }
             // dS of (query qb*32 + u*16 + 4 g + r, this lane's key) -> [query][key slot]
 #pragma unroll
@@ -713,24 +769,30 @@ __global__ __launch_bounds__(512) void attn_bwd_one_g_kernel(const half_t* __res
         if (kb * 32 < T) {
           const half8 df = at_frag(dSb + (kb >> 1) * 4096, qt * 16 + c16, (kb & 1) * 4 + g);
 #pragma unroll
-          for (int e = 0; e < 2; ++e) o[e] = mfma_16x16x32_f16(at_frag(Kt + (kb >> 1) * 4096, (dt0 + e) * 16 + c16, (kb & 1) * 4 + g), df, o[e]);
+          for (int e = 0; e < 2; ++e)          // [r6] dS as A (rows = queries), this wave's 32 columns of K^T in the order d = 16 dt0 + 2 c16 + e as B
+            o[e] = mfma_16x16x32_f16(df, at_frag_t(Kt + (kb >> 1) * 4096, dt0 * 16 + 2 * c16 + e, (kb & 1) * 4 + g), o[e]);
         }
       }
-      const int i = q0 + qt * 16 + c16;
-      if (i < T) {
+      // lane (c16, g): columns 16 dt0 + 2 c16, + 1 of queries g*4 + r -- the sixteen lanes of a row write 64 contiguous bytes (a wave owns half of the
+      // head's 64 columns; the other half is the wave 4 further on)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) store_h4(dbase + (size_t)i * ld + (dt0 + e) * 16 + g * 4, o[e][0], o[e][1], o[e][2], o[e][3]);
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + qt * 16 + g * 4 + r;
+        if (q < T) {
+          const half2 hv = {(half_t)o[0][r], (half_t)o[1][r]};
+          *reinterpret_cast<half2*>(dbase + (size_t)q * ld + dt0 * 16 + 2 * c16) = hv;
+        }
       }
     }
   }
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
-    const int j = (wave + 8 * jj) * 16 + c16;
-    if (j < T) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        store_h4(dbase + (size_t)j * ld + D + dt * 16 + g * 4, ok[jj][dt][0], ok[jj][dt][1], ok[jj][dt][2], ok[jj][dt][3]);
-        store_h4(dbase + (size_t)j * ld + 2 * D + dt * 16 + g * 4, ov[jj][dt][0], ov[jj][dt][1], ov[jj][dt][2], ov[jj][dt][3]);
+    for (int r = 0; r < 4; ++r) {
+      const int j = (wave + 8 * jj) * 16 + g * 4 + r;
+      if (j < T) {
+        store_h4(dbase + (size_t)j * ld + D + 4 * c16, ok[jj][0][r], ok[jj][1][r], ok[jj][2][r], ok[jj][3][r]);
+        store_h4(dbase + (size_t)j * ld + 2 * D + 4 * c16, ov[jj][0][r], ov[jj][1][r], ov[jj][2][r], ov[jj][3][r]);
       }
     }
   }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void blk_qkv_attn_kernel(const float* __restri
       else if (nt == 1) *reinterpret_cast<half4*>(Ks + at_off(tok, c >> 3) + (c & 7)) = hv;
       else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Vt[at_off(c + r, sl >> 3) + (sl & 7)] = hv[r];
+        for (int r = 0; r < 4; ++r) Vt[at_off_t(c + r, sl >> 3) + (sl & 7)] = hv[r];
       }
     }
   }

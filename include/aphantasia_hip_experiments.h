@@ -21,6 +21,9 @@ int aph_gemm_pack_frag(const void* d_Bt, int N, int K, void* d_out, void* stream
 /* Attention backward for sequences of 65 ... 256 tokens (ViT-B/16): 1 = one kernel that forms the probabilities and dS once and hands dS to
  * the dQ contraction through LDS (default), 0 = the dQ kernel + dK/dV kernel pair (each recomputes them).  Returns the previous value. */
 int aph_attn_set_bwd_one(int on);
+/* [r6] measurement variants of the T <= 56 attention backward (WRONG results; tools/exp/attn_ablate.py): 0 = the kernel, 1 = no products (zeros
+ * stored: loads + staging + stores), 2 = no stores (loads + staging + products), 3 = loads + staging only.  Returns the previous value. */
+int aph_attn_set_ablate(int mode);
 
 #ifdef __cplusplus
 }
