@@ -52,6 +52,7 @@ for STAGE in "$@"; do
         head -30 $O/${TAG}_kernel_stats_$c.txt | cut -c1-220
       done ;;
     calib)
+      [ -x tools/pmc/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/pmc/pmc_calib.hip -o tools/pmc/pmc_calib
       (cd /tmp && timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_calib_fetch -- $R/tools/pmc/pmc_calib > $O/${TAG}_calib.log 2>&1)
       (cd /tmp && timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_calib_write -- $R/tools/pmc/pmc_calib >> $O/${TAG}_calib.log 2>&1)
       python tools/pmc/calib_summary.py $O/${TAG}_calib_fetch $O/${TAG}_calib_write $O/${TAG}_pmc_calibration.json 2>&1 | tee $O/${TAG}_pmc_calibration.txt ;;
