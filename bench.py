@@ -653,13 +653,14 @@ def main():
             if a.config == 'c2' and cfg == CONFIGS['c2'] and world == 1 and a.f16:      # (the PMC passes run the default mode)
                 traffic, tsrc, stale, tmatch = pmc_traffic('r[0-9][0-9]_pmc_hbm_traffic*.json')
             # both floors of the family's average launch: matrix-core time of its FLOPs at the datasheet peak, and HBM time of its MEASURED fabric
-            # traffic (PMC summary of this build) at the achievable bandwidth; `bound` names the binding (larger) one, `frac_of_binding_floor` is
-            # that floor over the measured launch time (on counter traffic the family sits below the ridge point)
+            # traffic (PMC summary of this build) at the achievable bandwidth; `binding_floor` names the larger one, `frac_of_binding_floor` is
+            # that floor over the measured launch time (on counter traffic the family sits below the ridge point).  `bound`,
+            # `achieved`, `peak`, `unit`, `frac` stay ONE consistent triple -- the matrix-core figures every round has reported
             avg_us = ms_t * 1e3 / n_t
             floor_mfma_us = (fl_t / n_t) / (PEAK_TF * 1e12) * 1e6
             floor_hbm_us = (traffic / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6) if traffic else None
             binding = 'hbm' if (floor_hbm_us is not None and floor_hbm_us > floor_mfma_us) else 'mfma'
-            roof = dict(bound=binding, floors=dict(mfma_us=floor_mfma_us, hbm_us=floor_hbm_us, ridge_flop_per_byte=PEAK_TF * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9),
+            roof = dict(bound='mfma', binding_floor=binding, floors=dict(mfma_us=floor_mfma_us, hbm_us=floor_hbm_us, ridge_flop_per_byte=PEAK_TF * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9),
                                                    arithmetic_intensity_flop_per_byte=(fl_t / n_t / traffic) if traffic else None,
                                                    frac_of_binding_floor=(max(floor_mfma_us, floor_hbm_us or 0.0) / avg_us),
                                                    note='`achieved` / `peak` / `frac` stay the MFMA figures (algorithmic FLOPs over measured time against 2.5 PF) so that rounds compare; '
